@@ -1,0 +1,291 @@
+/*
+ * ptamd.h — C ABI of libptamd.so, the MI355X (gfx950) wavefront path tracer that sits behind the
+ * `pt::renderer_pt::Renderer` operator surface of teofum/platinum.
+ *
+ * The reference has no FFI layer: `Renderer` (src/renderer_pt/renderer_pt.hpp:28-73) is a concrete C++ class
+ * that the SDL2/ImGui frontend calls directly and that pulls the scene out of `Store&`.  This header is what a
+ * binding for that class would bind: one entry point per public `Renderer` member, Metal handles replaced by
+ * plain memory, the scene passed as a flat snapshot whose records keep the reference's exact byte layouts
+ * (src/renderer_pt/pt_shader_defs.hpp, src/core/mesh.hpp) so the frontend's buffers can be handed over as-is.
+ *
+ * Plain C: pointers and sizes only, no C++/torch/HIP types in any signature.
+ * Threading: one renderer = one caller thread (the reference is single-threaded, frontend.cpp:188-270).
+ * Errors: every call returns PT_OK (0) or a negative pt_error; pt_last_error() returns the message of the last
+ * failure on the calling thread (the reference prints to stderr and asserts: metal_utils.mm:172-214).
+ * There is NO CPU fallback: pt_create fails with PT_ERR_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef PTAMD_H
+#define PTAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1u
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* Enums (same numeric values as the reference)                                                                 */
+
+/* renderer_pt.hpp:21-26  enum Status */
+enum { PT_STATUS_BLOCKED = 0, PT_STATUS_READY = 1, PT_STATUS_BUSY = 4, PT_STATUS_DONE = 8 };
+/* renderer_pt.hpp:16-19  enum Integrators (kernel.metal:256 pathtracingKernel, :473 misKernel) */
+enum { PT_INTEGRATOR_SIMPLE = 0, PT_INTEGRATOR_MIS = 1 };
+/* pt_shader_defs.hpp:75-79  enum RendererFlags */
+enum { PT_FLAG_NONE = 0, PT_FLAG_MULTISCATTER_GGX = 1 << 0, PT_FLAG_GMON = 1 << 1 };
+/* pt_shader_defs.hpp:85-90  MaterialGPU::MaterialFlags */
+enum {
+  PT_MATERIAL_THIN_DIELECTRIC = 1 << 0,
+  PT_MATERIAL_USE_ALPHA = 1 << 1,
+  PT_MATERIAL_EMISSIVE = 1 << 2,
+  PT_MATERIAL_ANISOTROPIC = 1 << 3
+};
+
+typedef enum pt_error {
+  PT_OK = 0,
+  PT_ERR_INVALID_ARGUMENT = -1,
+  PT_ERR_NO_DEVICE = -2,     /* no usable HIP device: the library never falls back to the CPU */
+  PT_ERR_HIP = -3,           /* a HIP runtime call failed; message has file:line and hipGetErrorString */
+  PT_ERR_OUT_OF_MEMORY = -4,
+  PT_ERR_BAD_STATE = -5,     /* e.g. pt_render_step before pt_start_render */
+  PT_ERR_UNSUPPORTED = -6,   /* a scene feature of a "next" row (textures, env map) */
+  PT_ERR_BAD_LUT = -7
+} pt_error;
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* Scene snapshot: what crosses the ABI instead of `Store&`.  Byte layouts are the reference's.                */
+
+/* simd float3: 16-byte stride (renderer_pt.cpp:231, core/mesh.cpp:67-69) */
+typedef struct pt_float3 { float x, y, z, _pad; } pt_float3;
+
+/* core/mesh.hpp:17-21  VertexData, 48 B: normal @0, tangent(xyzw) @16, texCoords @32 */
+typedef struct pt_vertex_data {
+  pt_float3 normal;
+  float tangent[4];
+  float texCoords[2];
+  float _pad[2];
+} pt_vertex_data;
+
+/* pt_shader_defs.hpp:84-103  MaterialGPU, 96 B */
+typedef struct pt_material_gpu {
+  float baseColor[4];          /* @0  */
+  pt_float3 emission;          /* @16 */
+  float emissionStrength;      /* @32 */
+  float roughness;             /* @36 */
+  float metallic;              /* @40 */
+  float transmission;          /* @44 */
+  float ior;                   /* @48 */
+  float anisotropy;            /* @52 */
+  float anisotropyRotation;    /* @56 */
+  float clearcoat;             /* @60 */
+  float clearcoatRoughness;    /* @64 */
+  int32_t flags;               /* @68 */
+  int32_t baseTextureId;       /* @72 */
+  int32_t rmTextureId;         /* @76 */
+  int32_t transmissionTextureId; /* @80 */
+  int32_t clearcoatTextureId;  /* @84 */
+  int32_t emissionTextureId;   /* @88 */
+  int32_t normalTextureId;     /* @92 */
+} pt_material_gpu;
+
+/* One mesh = the four shared buffers of core/mesh.hpp:23-60.  `indices` doubles as PrimitiveData[]
+ * (pt_shader_defs.hpp:48-50, renderer_pt.cpp:237-239). */
+typedef struct pt_mesh {
+  const pt_float3* positions;        /* vertex_count x 16 B */
+  const pt_vertex_data* vertex_data; /* vertex_count x 48 B */
+  const uint32_t* indices;           /* 3 * triangle_count */
+  const uint32_t* material_slots;    /* triangle_count (core/mesh.hpp:32,55) */
+  uint32_t vertex_count;
+  uint32_t triangle_count;
+} pt_mesh;
+
+/* MTLAccelerationStructureInstanceDescriptor, 64 B packed (filled at renderer_pt.cpp:706-739):
+ * 4 columns x packed float3 @0, options @48, mask @52, intersectionFunctionTableOffset @56,
+ * accelerationStructureIndex (= mesh index) @60 */
+typedef struct pt_instance {
+  float transform[4][3];
+  uint32_t options;
+  uint32_t mask;
+  uint32_t intersectionFunctionTableOffset;
+  uint32_t accelerationStructureIndex;
+} pt_instance;
+
+/* InstanceResource (pt_shader_defs.hpp:126-128): the per-INSTANCE material array, indexed by the
+ * triangle's material slot (renderer_pt.cpp:560-640 duplicates materials per instance). */
+typedef struct pt_instance_materials {
+  const pt_material_gpu* materials;
+  uint32_t material_count;
+  uint32_t _pad;
+} pt_instance_materials;
+
+/* Camera node: world matrix (scene.cpp:515-534, column-major float4x4) + core/camera.hpp:10-18.
+ * The library derives CameraData exactly as Renderer::updateConstants (renderer_pt.cpp:965-1021). */
+typedef struct pt_camera {
+  float world[4][4];        /* columns */
+  float sensor_size[2];     /* mm, default {36,24} */
+  float focal_length;       /* mm */
+  float aperture;           /* f-number, 0 = pinhole */
+  uint32_t aperture_blades;
+  float roundness;
+  float bokeh_power;
+  float focus_distance;
+} pt_camera;
+
+/* core/colorspace.hpp:22-42: CIE xy chromaticities of the primaries and the white point */
+typedef struct pt_colorspace { float r[2], g[2], b[2], w[2]; } pt_colorspace;
+
+typedef struct pt_scene_snapshot {
+  const pt_mesh* meshes;
+  uint32_t mesh_count;
+  uint32_t instance_count;
+  const pt_instance* instances;                    /* instance_count */
+  const pt_instance_materials* instance_materials; /* instance_count */
+  pt_camera camera;
+  /* textures / environment map: SURVEY §8f row N3, not part of this ABI version; texture ids must be -1 */
+} pt_scene_snapshot;
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* Derived device constants, exported for parity checks (pt_get_constants)                                     */
+
+/* pt_shader_defs.hpp:52-61 CameraData, 80 B */
+typedef struct pt_camera_data {
+  pt_float3 position, topLeft, pixelDeltaU, pixelDeltaV;
+  float apertureRadius;
+  uint32_t apertureBlades;
+  float apertureRoundness;
+  float bokehPower;
+} pt_camera_data;
+
+/* pt_shader_defs.hpp:105-115 Constants, 176 B */
+typedef struct pt_constants {
+  uint32_t frameIdx, spp, gmonBuckets;
+  uint32_t lightCount;
+  uint32_t envLightCount;
+  uint32_t lutSizeE, lutSizeEavg;
+  int32_t flags;
+  float totalLightPower;
+  uint32_t _pad0;
+  uint32_t size[2];
+  pt_float3 idt[3];  /* float3x3 columns */
+  pt_camera_data camera;
+} pt_constants;
+
+/* pt_shader_defs.hpp:63-68 AreaLight, 48 B (built by the library as renderer_pt.cpp:838-917) */
+typedef struct pt_area_light {
+  uint32_t instanceIdx;
+  uint32_t indices[3];
+  float area, power, cumulativePower;
+  float _pad;
+  pt_float3 emission;
+} pt_area_light;
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* Renderer                                                                                                      */
+
+typedef struct pt_renderer pt_renderer;
+
+/* Renderer::Renderer(device, queue, store) (renderer_pt.hpp:28-32, renderer_pt.cpp:18-60): builds the
+ * pipelines and loads the 8 GGX energy LUTs (renderer_pt.cpp:385-446). */
+typedef struct pt_create_info {
+  uint32_t abi_version;   /* PT_ABI_VERSION */
+  int32_t device_ordinal; /* HIP device; the reference takes the MTL::Device of the window */
+  const void* lut_blob;   /* the LUT blob (tools/make_lut_blob.py) in host memory, or NULL ... */
+  uint64_t lut_blob_size;
+  const char* lut_path;   /* ... to read it from this file (NULL: $PTAMD_LUT_PATH) */
+} pt_create_info;
+
+int pt_create(const pt_create_info* info, pt_renderer** out);
+/* Renderer::~Renderer (renderer_pt.hpp:34) */
+void pt_destroy(pt_renderer* r);
+
+/* Parameters of Renderer::startRender(camera, size, spp, gmonBuckets, workingSpace, flags)
+ * (renderer_pt.hpp:38-45) + selectKernel (:47-53) + what the reference fixes at compile time or lacks. */
+typedef struct pt_render_params {
+  uint32_t width, height;      /* viewport size */
+  uint32_t spp;                /* samples this renderer accumulates (m_accumulationFrames) */
+  uint32_t gmon_buckets;       /* used only with PT_FLAG_GMON; constants.gmonBuckets is 1 otherwise */
+  int32_t flags;               /* PT_FLAG_* */
+  uint32_t integrator;         /* PT_INTEGRATOR_* (default MIS, renderer_pt.hpp:98) */
+  pt_colorspace working_space; /* default BT2020 (pt_viewport.hpp:95) */
+  uint32_t max_bounces;        /* NEW: kernel.metal:5 hard-codes 50; 1..50 */
+  uint32_t first_sample;       /* NEW: frameIdx of this renderer's first sample (multi-GPU shards) */
+  uint32_t samples_in_flight;  /* NEW: samples traced concurrently per batch; 0 = auto */
+  uint32_t _reserved;
+  void* external_accumulator;  /* optional DEVICE pointer to W*H float4; NULL = library-owned */
+  void* stream;                /* optional hipStream_t to enqueue on; NULL = library-owned stream */
+} pt_render_params;
+
+/* Renderer::startRender + the rebuild* half of the first Renderer::render() (renderer_pt.cpp:72-111,
+ * 199-217): copies the snapshot to HBM, builds light table, constants and the LBVH.  The caller owns the
+ * snapshot memory only until this returns. Resets progress to 0. */
+int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_render_params* params);
+
+/* Renderer::render() steady state (renderer_pt.cpp:113-197): enqueue up to `max_spp_this_call` further
+ * samples (the reference encodes exactly 1) and return without waiting. 0 = all remaining samples. */
+int pt_render_step(pt_renderer* r, uint32_t max_spp_this_call);
+/* Block until everything enqueued so far has completed (the reference only blocks in readback). */
+int pt_wait(pt_renderer* r);
+
+/* Renderer::status() (renderer_pt.cpp:1023-1031), renderProgress() (:1033-1035), renderTime() (:1037) */
+int pt_status(const pt_renderer* r);
+int pt_progress(const pt_renderer* r, uint64_t* accumulated, uint64_t* total);
+uint64_t pt_render_time_ms(const pt_renderer* r);
+
+/* The float accumulator: W*H RGBA32F, row-major, top-left origin, running mean, alpha 1
+ * (renderer_pt.cpp:812-821, kernel.metal:672-684).  Blocks like readbackRenderTarget (:1039-1059). */
+int pt_read_accumulator(pt_renderer* r, float* rgba_out);
+/* Device address of the accumulator (for an RCCL reduce by the caller); NULL before pt_start_render. */
+void* pt_accumulator_device_ptr(pt_renderer* r);
+
+const char* pt_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* Parity / measurement surface (no reference counterpart; used by tests and bench.py)                          */
+
+int pt_get_constants(const pt_renderer* r, pt_constants* out);
+/* Copies up to `capacity` lights; returns the light count in *count. */
+int pt_get_lights(const pt_renderer* r, pt_area_light* out, uint32_t capacity, uint32_t* count);
+
+/* Closest-hit record of the camera ray of every pixel for sample `sample_idx` (raygen + traversal only). */
+typedef struct pt_hit_record {
+  float t, u, v;
+  int32_t instance; /* -1 = miss */
+  int32_t primitive;
+} pt_hit_record;
+int pt_trace_primary(pt_renderer* r, uint32_t sample_idx, pt_hit_record* out /* W*H */);
+
+/* Trace ONE sample without touching the accumulator; returns its radiance and the (instance, primitive)
+ * hit at every bounce of every pixel's path (-1,-1 where the path was already dead or missed).
+ *   radiance_out : W*H*4 floats (rgb, 1)               or NULL
+ *   hits_out     : max_bounces * W*H * 2 int32          or NULL */
+int pt_debug_sample(pt_renderer* r, uint32_t sample_idx, float* radiance_out, int32_t* hits_out);
+
+typedef struct pt_stats {
+  uint64_t triangles;          /* flattened world-space triangles */
+  uint64_t bvh_nodes;
+  uint32_t bvh_max_depth;
+  uint32_t samples_in_flight;
+  double upload_ms;            /* snapshot -> HBM */
+  double bvh_build_ms;         /* LBVH build (device time) */
+  uint64_t closest_rays;       /* rays traced since pt_start_render */
+  uint64_t shadow_rays;
+  uint64_t shaded_hits;
+  uint64_t paths;              /* pixel*samples started */
+  /* device time per kernel class since pt_start_render, HIP events on the launch stream */
+  double ms_raygen, ms_closest, ms_shade, ms_shadow, ms_accumulate;
+  uint64_t launches_closest, launches_shadow;
+  /* instrumented traversal (pt_measure_traversal): mean BVH nodes / triangles fetched per ray */
+  double nodes_per_closest_ray, tris_per_closest_ray;
+  double nodes_per_shadow_ray, tris_per_shadow_ray;
+} pt_stats;
+int pt_get_stats(pt_renderer* r, pt_stats* out);
+/* Enable per-kernel HIP-event timing (adds two event records per launch). */
+int pt_set_profiling(pt_renderer* r, int enabled);
+/* Run one instrumented sample (outside any timed region) to count node/triangle fetches per ray. */
+int pt_measure_traversal(pt_renderer* r, uint32_t sample_idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTAMD_H */

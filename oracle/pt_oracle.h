@@ -1,0 +1,49 @@
+// TEST INFRASTRUCTURE — C API of the CPU oracle (oracle/pt_oracle.cpp). See the header comment there.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this.
+#pragma once
+#include <stdint.h>
+#include "../include/ptamd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_scene orc_scene;
+
+typedef struct orc_stats {
+  uint64_t triangles, bvh_nodes;
+  uint64_t closest_rays, shadow_rays, shaded_hits, paths;
+  uint64_t nodes_closest, tris_closest, nodes_shadow, tris_shadow;
+} orc_stats;
+
+// use_bvh = 0: brute force over every triangle (the definition); 1: oracle-private median-split BVH (same answers).
+orc_scene* orc_scene_create(const pt_scene_snapshot* snap, const pt_render_params* params, const void* lut_blob,
+                            uint64_t lut_size, int use_bvh);
+void orc_scene_destroy(orc_scene* sc);
+int orc_get_constants(const orc_scene* sc, pt_constants* out);
+int orc_get_lights(const orc_scene* sc, pt_area_light* out, uint32_t capacity, uint32_t* count);
+int orc_render(orc_scene* sc, uint32_t first_sample, uint32_t nsamples, float* acc, uint32_t acc_n0, int threads,
+               int count_traversal);
+int orc_trace_primary(orc_scene* sc, uint32_t sample_idx, pt_hit_record* out);
+int orc_debug_sample(orc_scene* sc, uint32_t sample_idx, float* radiance_out, int32_t* hits_out, int threads);
+int orc_get_stats(const orc_scene* sc, orc_stats* out);
+
+uint32_t orc_halton_offset(uint32_t x, uint32_t y, uint32_t sample);
+void orc_pcg4d(const uint32_t in[4], uint32_t out[4]);
+float orc_halton(uint32_t i, uint32_t d);
+uint32_t orc_prime(uint32_t d);
+float orc_fresnel(float cosTheta, float ior);
+float orc_avg_dielectric_fresnel_fit(float ior);
+void orc_sincos(float x, float* s, float* c);
+float orc_log2(float x);
+float orc_exp2(float x);
+void orc_sample_cosine_hemisphere(float u0, float u1, float out[3]);
+void orc_sample_tri_uniform(float u0, float u1, float out[2]);
+float orc_lut_sample(const orc_scene* sc, int which, float cx, float cy, float cz);
+void orc_bsdf_sample(const orc_scene* sc, const pt_material_gpu* mat, const float wo[3], const float r[4], const float rc[2],
+                     float out_sample[11]);
+void orc_bsdf_eval(const orc_scene* sc, const pt_material_gpu* mat, const float wo[3], const float wi[3], float out_eval[4]);
+
+#ifdef __cplusplus
+}
+#endif

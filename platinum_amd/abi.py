@@ -1,0 +1,193 @@
+"""ctypes mirror of include/ptamd.h and the loader of libptamd.so.
+
+This is the reference-side binding a maintainer would write for `pt::renderer_pt::Renderer`
+(src/renderer_pt/renderer_pt.hpp:28-73) — see INTEGRATION.md.  There is no CPU fallback: if the HIP
+library is missing or cannot find a device, loading / pt_create raises.
+"""
+import ctypes as C
+import os
+
+PT_ABI_VERSION = 1
+
+# renderer_pt.hpp:21-26
+STATUS_BLOCKED, STATUS_READY, STATUS_BUSY, STATUS_DONE = 0, 1, 4, 8
+# renderer_pt.hpp:16-19
+INTEGRATOR_SIMPLE, INTEGRATOR_MIS = 0, 1
+# pt_shader_defs.hpp:75-79
+FLAG_NONE, FLAG_MULTISCATTER_GGX, FLAG_GMON = 0, 1, 2
+# pt_shader_defs.hpp:85-90
+MATERIAL_THIN_DIELECTRIC, MATERIAL_USE_ALPHA, MATERIAL_EMISSIVE, MATERIAL_ANISOTROPIC = 1, 2, 4, 8
+
+
+class Float3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("_pad", C.c_float)]
+
+
+class VertexData(C.Structure):
+    _fields_ = [("normal", Float3), ("tangent", C.c_float * 4), ("texCoords", C.c_float * 2), ("_pad", C.c_float * 2)]
+
+
+class MaterialGPU(C.Structure):
+    _fields_ = [
+        ("baseColor", C.c_float * 4), ("emission", Float3), ("emissionStrength", C.c_float),
+        ("roughness", C.c_float), ("metallic", C.c_float), ("transmission", C.c_float), ("ior", C.c_float),
+        ("anisotropy", C.c_float), ("anisotropyRotation", C.c_float), ("clearcoat", C.c_float),
+        ("clearcoatRoughness", C.c_float), ("flags", C.c_int32), ("baseTextureId", C.c_int32),
+        ("rmTextureId", C.c_int32), ("transmissionTextureId", C.c_int32), ("clearcoatTextureId", C.c_int32),
+        ("emissionTextureId", C.c_int32), ("normalTextureId", C.c_int32),
+    ]
+
+
+class Mesh(C.Structure):
+    _fields_ = [
+        ("positions", C.c_void_p), ("vertex_data", C.c_void_p), ("indices", C.c_void_p),
+        ("material_slots", C.c_void_p), ("vertex_count", C.c_uint32), ("triangle_count", C.c_uint32),
+    ]
+
+
+class Instance(C.Structure):
+    _fields_ = [
+        ("transform", (C.c_float * 3) * 4), ("options", C.c_uint32), ("mask", C.c_uint32),
+        ("intersectionFunctionTableOffset", C.c_uint32), ("accelerationStructureIndex", C.c_uint32),
+    ]
+
+
+class InstanceMaterials(C.Structure):
+    _fields_ = [("materials", C.c_void_p), ("material_count", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [
+        ("world", (C.c_float * 4) * 4), ("sensor_size", C.c_float * 2), ("focal_length", C.c_float),
+        ("aperture", C.c_float), ("aperture_blades", C.c_uint32), ("roundness", C.c_float),
+        ("bokeh_power", C.c_float), ("focus_distance", C.c_float),
+    ]
+
+
+class Colorspace(C.Structure):
+    _fields_ = [("r", C.c_float * 2), ("g", C.c_float * 2), ("b", C.c_float * 2), ("w", C.c_float * 2)]
+
+
+class SceneSnapshot(C.Structure):
+    _fields_ = [
+        ("meshes", C.c_void_p), ("mesh_count", C.c_uint32), ("instance_count", C.c_uint32),
+        ("instances", C.c_void_p), ("instance_materials", C.c_void_p), ("camera", Camera),
+    ]
+
+
+class CameraData(C.Structure):
+    _fields_ = [
+        ("position", Float3), ("topLeft", Float3), ("pixelDeltaU", Float3), ("pixelDeltaV", Float3),
+        ("apertureRadius", C.c_float), ("apertureBlades", C.c_uint32), ("apertureRoundness", C.c_float),
+        ("bokehPower", C.c_float),
+    ]
+
+
+class Constants(C.Structure):
+    _fields_ = [
+        ("frameIdx", C.c_uint32), ("spp", C.c_uint32), ("gmonBuckets", C.c_uint32), ("lightCount", C.c_uint32),
+        ("envLightCount", C.c_uint32), ("lutSizeE", C.c_uint32), ("lutSizeEavg", C.c_uint32), ("flags", C.c_int32),
+        ("totalLightPower", C.c_float), ("_pad0", C.c_uint32), ("size", C.c_uint32 * 2), ("idt", Float3 * 3),
+        ("camera", CameraData),
+    ]
+
+
+class AreaLight(C.Structure):
+    _fields_ = [
+        ("instanceIdx", C.c_uint32), ("indices", C.c_uint32 * 3), ("area", C.c_float), ("power", C.c_float),
+        ("cumulativePower", C.c_float), ("_pad", C.c_float), ("emission", Float3),
+    ]
+
+
+class CreateInfo(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("device_ordinal", C.c_int32), ("lut_blob", C.c_void_p),
+        ("lut_blob_size", C.c_uint64), ("lut_path", C.c_char_p),
+    ]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("gmon_buckets", C.c_uint32),
+        ("flags", C.c_int32), ("integrator", C.c_uint32), ("working_space", Colorspace),
+        ("max_bounces", C.c_uint32), ("first_sample", C.c_uint32), ("samples_in_flight", C.c_uint32),
+        ("_reserved", C.c_uint32), ("external_accumulator", C.c_void_p), ("stream", C.c_void_p),
+    ]
+
+
+class HitRecord(C.Structure):
+    _fields_ = [("t", C.c_float), ("u", C.c_float), ("v", C.c_float), ("instance", C.c_int32), ("primitive", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("triangles", C.c_uint64), ("bvh_nodes", C.c_uint64), ("bvh_max_depth", C.c_uint32),
+        ("samples_in_flight", C.c_uint32), ("upload_ms", C.c_double), ("bvh_build_ms", C.c_double),
+        ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("shaded_hits", C.c_uint64), ("paths", C.c_uint64),
+        ("ms_raygen", C.c_double), ("ms_closest", C.c_double), ("ms_shade", C.c_double), ("ms_shadow", C.c_double),
+        ("ms_accumulate", C.c_double), ("launches_closest", C.c_uint64), ("launches_shadow", C.c_uint64),
+        ("nodes_per_closest_ray", C.c_double), ("tris_per_closest_ray", C.c_double),
+        ("nodes_per_shadow_ray", C.c_double), ("tris_per_shadow_ray", C.c_double),
+    ]
+
+
+assert C.sizeof(Float3) == 16 and C.sizeof(VertexData) == 48 and C.sizeof(MaterialGPU) == 96
+assert C.sizeof(Instance) == 64 and C.sizeof(CameraData) == 80 and C.sizeof(Constants) == 176
+assert C.sizeof(AreaLight) == 48
+
+# every symbol include/ptamd.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("pt_create", C.c_int, [C.POINTER(CreateInfo), C.POINTER(C.c_void_p)]),
+    ("pt_destroy", None, [C.c_void_p]),
+    ("pt_start_render", C.c_int, [C.c_void_p, C.POINTER(SceneSnapshot), C.POINTER(RenderParams)]),
+    ("pt_render_step", C.c_int, [C.c_void_p, C.c_uint32]),
+    ("pt_wait", C.c_int, [C.c_void_p]),
+    ("pt_status", C.c_int, [C.c_void_p]),
+    ("pt_progress", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("pt_render_time_ms", C.c_uint64, [C.c_void_p]),
+    ("pt_read_accumulator", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("pt_accumulator_device_ptr", C.c_void_p, [C.c_void_p]),
+    ("pt_last_error", C.c_char_p, []),
+    ("pt_get_constants", C.c_int, [C.c_void_p, C.POINTER(Constants)]),
+    ("pt_get_lights", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    ("pt_trace_primary", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("pt_debug_sample", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("pt_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    ("pt_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
+    ("pt_measure_traversal", C.c_int, [C.c_void_p, C.c_uint32]),
+]
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "csrc", "libptamd.so")
+LUT_PATH = os.path.join(_PKG_DIR, "data", "ggx_luts.bin")
+
+_lib = None
+
+
+class PtamdError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """Load libptamd.so and bind every declared symbol.  Raises if the library is not built — there is
+    deliberately no fallback implementation."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("PTAMD_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise PtamdError(f"{p} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()')")
+    lib = C.CDLL(p)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(lib, code):
+    if code != 0:
+        msg = lib.pt_last_error()
+        raise PtamdError(f"ptamd error {code}: {msg.decode() if msg else '?'}")

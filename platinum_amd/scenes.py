@@ -1,0 +1,446 @@
+"""Host-side scene model: the part of the reference's `Store`/`Scene` the path tracer consumes, restated in
+numpy so that headless drivers (tests, bench) can hand the renderer the same flattened snapshot the
+SDL2/ImGui frontend would.
+
+Mirrors (by behaviour, fp32 throughout):
+  core/primitives.cpp:7-190        plane / cube / sphere / cornellBox
+  core/transform.hpp:36-51         Transform::matrix()  (T*Ry*Rx*Rz*S, or inverse(lookAt)*S when tracking)
+  utils/matrices.cpp:9-145         translation / rotation_* / scaling / lookAt
+  core/camera.hpp:10-51            Camera
+  frontend/windows/scene_explorer.cpp:50-90   the "Cornell Box" and "Camera" menu entries
+  core/scene.cpp:479-534           getInstances(): depth-first hierarchy walk -> Instance{mesh, worldMatrix}
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import abi
+
+f32 = np.float32
+
+# core/colorspace.cpp:5-7, colorspace.hpp:47
+WHITEPOINT_D65 = (0.3127, 0.3290)
+BT709 = ((0.640, 0.330), (0.300, 0.600), (0.150, 0.060), WHITEPOINT_D65)
+DISPLAY_P3 = ((0.680, 0.320), (0.265, 0.690), (0.150, 0.060), WHITEPOINT_D65)
+BT2020 = ((0.708, 0.292), (0.170, 0.797), (0.131, 0.046), WHITEPOINT_D65)
+
+
+def colorspace(cs=BT2020):
+    out = abi.Colorspace()
+    for name, v in zip("rgbw", cs):
+        getattr(out, name)[0] = v[0]
+        getattr(out, name)[1] = v[1]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# matrices (column-major 4x4 like simd: M[c] is column c) — utils/matrices.cpp
+# ---------------------------------------------------------------------------------------------------------------
+def _cols(*cols):
+    return np.array(cols, dtype=f32)  # shape (4,4): [column][row]
+
+
+def mat_identity():
+    return np.eye(4, dtype=f32)
+
+
+def mat_translation(t):
+    return _cols([1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [t[0], t[1], t[2], 1])
+
+
+def mat_scaling(s):
+    s = np.broadcast_to(np.asarray(s, dtype=f32), (3,))
+    return _cols([s[0], 0, 0, 0], [0, s[1], 0, 0], [0, 0, s[2], 0], [0, 0, 0, 1])
+
+
+def mat_rotation_x(a):
+    c, s = f32(np.cos(f32(a))), f32(np.sin(f32(a)))
+    return _cols([1, 0, 0, 0], [0, c, s, 0], [0, -s, c, 0], [0, 0, 0, 1])
+
+
+def mat_rotation_y(a):
+    c, s = f32(np.cos(f32(a))), f32(np.sin(f32(a)))
+    return _cols([c, 0, -s, 0], [0, 1, 0, 0], [s, 0, c, 0], [0, 0, 0, 1])
+
+
+def mat_rotation_z(a):
+    c, s = f32(np.cos(f32(a))), f32(np.sin(f32(a)))
+    return _cols([c, s, 0, 0], [-s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1])
+
+
+def mat_mul(a, b):
+    """simd a * b for column-major storage [col][row]."""
+    # (a*b)[c][r] = sum_k a[k][r] * b[c][k]
+    return np.einsum("kr,ck->cr", a.astype(f32), b.astype(f32)).astype(f32)
+
+
+def _normalize(v):
+    v = np.asarray(v, dtype=f32)
+    return (v / f32(np.sqrt(np.dot(v, v)))).astype(f32)
+
+
+def mat_look_at(position, target, up):  # utils/matrices.cpp:132-145
+    position = np.asarray(position, dtype=f32)
+    target = np.asarray(target, dtype=f32)
+    if np.array_equal(position, target):
+        return mat_identity()
+    f = _normalize(position - target)
+    s = _normalize(np.cross(np.asarray(up, dtype=f32), f))
+    u = np.cross(f, s).astype(f32)
+    return _cols([s[0], u[0], f[0], 0], [s[1], u[1], f[1], 0], [s[2], u[2], f[2], 0],
+                 [-np.dot(s, position), -np.dot(u, position), -np.dot(f, position), 1])
+
+
+def mat_inverse(m):
+    # [col][row] storage is the transpose of the usual row-major matrix; inverse commutes with transpose.
+    return np.linalg.inv(m.astype(np.float64)).astype(f32)
+
+
+@dataclass
+class Transform:  # core/transform.hpp:19-51
+    translation: tuple = (0.0, 0.0, 0.0)
+    rotation: tuple = (0.0, 0.0, 0.0)
+    scale: tuple = (1.0, 1.0, 1.0)
+    target: tuple = (0.0, 0.0, 0.0)
+    track: bool = False
+
+    def matrix(self):
+        S = mat_scaling(self.scale)
+        if self.track:
+            t, g = self.translation, self.target
+            up = (0, 0, 1) if (t[0] == g[0] and t[2] == g[2]) else (0, 1, 0)
+            L = mat_inverse(mat_look_at(t, g, up))
+            return mat_mul(L, S)
+        T = mat_translation(self.translation)
+        Rx, Ry, Rz = mat_rotation_x(self.rotation[0]), mat_rotation_y(self.rotation[1]), mat_rotation_z(self.rotation[2])
+        return mat_mul(mat_mul(mat_mul(mat_mul(T, Ry), Rx), Rz), S)
+
+
+@dataclass
+class Camera:  # core/camera.hpp:10-18
+    sensor_size: tuple = (36.0, 24.0)
+    focal_length: float = 50.0
+    aperture: float = 0.0
+    aperture_blades: int = 7
+    roundness: float = 1.0
+    bokeh_power: float = 0.0
+    focus_distance: float = 1.0
+
+    @staticmethod
+    def with_focal_length(f, sensor_size=(36.0, 24.0), aperture=0.0):  # camera.hpp:20-30
+        return Camera(sensor_size=sensor_size, focal_length=f, aperture=aperture)
+
+
+@dataclass
+class Material:  # core/material.hpp:15-49 (texture slots are a "next" row)
+    name: str = ""
+    base_color: tuple = (0.8, 0.8, 0.8, 1.0)
+    emission: tuple = (0.0, 0.0, 0.0)
+    emission_strength: float = 0.0
+    roughness: float = 1.0
+    metallic: float = 0.0
+    transmission: float = 0.0
+    ior: float = 1.5
+    anisotropy: float = 0.0
+    anisotropy_rotation: float = 0.0
+    clearcoat: float = 0.0
+    clearcoat_roughness: float = 0.05
+    thin_transmission: bool = False
+
+    def is_emissive(self):  # material.hpp:44-47
+        e = np.asarray(self.emission, dtype=f32) * f32(self.emission_strength)
+        return float(np.dot(e, e)) > 0.0
+
+    def to_gpu(self):  # renderer_pt.cpp:583-633
+        m = abi.MaterialGPU()
+        for i in range(4):
+            m.baseColor[i] = self.base_color[i]
+        m.emission = abi.Float3(self.emission[0], self.emission[1], self.emission[2], 0.0)
+        m.emissionStrength = self.emission_strength
+        m.roughness, m.metallic, m.transmission, m.ior = self.roughness, self.metallic, self.transmission, self.ior
+        m.anisotropy, m.anisotropyRotation = self.anisotropy, self.anisotropy_rotation
+        m.clearcoat, m.clearcoatRoughness = self.clearcoat, self.clearcoat_roughness
+        flags = 0
+        if self.thin_transmission:
+            flags |= abi.MATERIAL_THIN_DIELECTRIC
+        if self.base_color[3] < 1.0:
+            flags |= abi.MATERIAL_USE_ALPHA
+        if self.anisotropy != 0.0:
+            flags |= abi.MATERIAL_ANISOTROPIC
+        if self.is_emissive():
+            flags |= abi.MATERIAL_EMISSIVE
+        m.flags = flags
+        m.baseTextureId = m.rmTextureId = m.transmissionTextureId = -1
+        m.clearcoatTextureId = m.emissionTextureId = m.normalTextureId = -1
+        return m
+
+
+@dataclass
+class MeshData:  # core/mesh.hpp:23-60 — the four shared buffers
+    positions: np.ndarray      # (V,4) f32, 16-byte float3
+    vertex_data: np.ndarray    # (V,12) f32, 48-byte VertexData
+    indices: np.ndarray        # (3T,) u32
+    material_slots: np.ndarray # (T,) u32
+
+    @property
+    def triangle_count(self):
+        return len(self.indices) // 3
+
+
+def _make_mesh(vertices, normals, tangents, uvs, indices, mat_indices):
+    v = np.zeros((len(vertices), 4), dtype=f32)
+    v[:, :3] = np.asarray(vertices, dtype=f32)
+    vd = np.zeros((len(vertices), 12), dtype=f32)
+    vd[:, 0:3] = np.asarray(normals, dtype=f32)
+    vd[:, 4:8] = np.asarray(tangents, dtype=f32)
+    vd[:, 8:10] = np.asarray(uvs, dtype=f32)
+    return MeshData(v, vd, np.asarray(indices, dtype=np.uint32), np.asarray(mat_indices, dtype=np.uint32))
+
+
+_FACE_POS = np.array([[1, -1], [1, 1], [-1, -1], [-1, 1]], dtype=f32)
+
+
+def plane(side):  # primitives.cpp:7-29
+    h = f32(side) * f32(0.5)
+    verts = np.array([[-h, 0, -h], [h, 0, -h], [-h, 0, h], [h, 0, h]], dtype=f32)
+    uvs = (verts[:, [0, 2]] + h) / (f32(2.0) * h)
+    return _make_mesh(verts, [[0, 1, 0]] * 4, [[1, 0, 0, 0]] * 4, uvs, [0, 2, 1, 1, 2, 3], [0, 0])
+
+
+def _box_faces(face_normals, h, sign, offset):
+    verts, normals, tangents, uvs, indices = [], [], [], [], []
+    for i, fn in enumerate(face_normals):
+        fn = np.asarray(fn, dtype=f32)
+        up = np.array([1, 0, 0], dtype=f32) if abs(fn[1]) == 1.0 else np.array([0, 1, 0], dtype=f32)
+        right = np.cross(up, fn).astype(f32)
+        for fp in _FACE_POS:
+            verts.append((sign * fn + up * fp[0] + right * fp[1]) * f32(h) + np.asarray(offset, dtype=f32))
+            normals.append(fn)
+            tangents.append([right[0], right[1], right[2], 1.0])
+            uvs.append(fp)
+        indices += [4 * i + 0, 4 * i + 2, 4 * i + 1, 4 * i + 1, 4 * i + 2, 4 * i + 3]
+    return verts, normals, tangents, uvs, indices
+
+
+def cube(side):  # primitives.cpp:31-77
+    fns = [[0, 0, 1], [1, 0, 0], [0, 0, -1], [-1, 0, 0], [0, 1, 0], [0, -1, 0]]
+    v, n, t, uv, idx = _box_faces(fns, f32(side) * f32(0.5), f32(1.0), [0, 0, 0])
+    return _make_mesh(v, n, t, uv, idx, [0] * 12)
+
+
+def sphere(radius, lat, lng):  # primitives.cpp:79-130
+    pi = f32(np.pi)
+    d_lat = pi / f32(lat)
+    d_lng = pi / f32(lng) * f32(2.0)
+    i = np.arange(lat + 1, dtype=f32)
+    j = np.arange(lng + 1, dtype=f32)
+    phi = (f32(0.5) * pi - i * d_lat).astype(f32)
+    theta = (j * d_lng).astype(f32)
+    c = np.cos(phi).astype(f32)
+    pos = np.stack([np.outer(c, np.cos(theta).astype(f32)), np.repeat(np.sin(phi).astype(f32)[:, None], lng + 1, 1),
+                    np.outer(c, np.sin(theta).astype(f32))], axis=-1).astype(f32).reshape(-1, 3)
+    tang = np.stack([np.tile(-np.sin(theta), lat + 1), np.zeros((lat + 1) * (lng + 1)), np.tile(np.cos(theta), lat + 1),
+                     np.ones((lat + 1) * (lng + 1))], axis=-1).astype(f32)
+    uv = np.stack([np.tile(j / f32(lng), lat + 1), np.repeat(i / f32(lat), lng + 1)], axis=-1).astype(f32)
+    ii, jj = np.meshgrid(np.arange(1, lat + 1), np.arange(1, lng + 1), indexing="ij")
+    ii, jj = ii.ravel(), jj.ravel()
+    v0 = (ii - 1) * (lng + 1) + (jj - 1)
+    v1 = (ii - 1) * (lng + 1) + jj
+    v2 = ii * (lng + 1) + (jj - 1)
+    v3 = ii * (lng + 1) + jj
+    indices = np.stack([v0, v1, v2, v1, v3, v2], axis=-1).ravel()
+    return _make_mesh(pos * f32(radius), pos, tang, uv, indices, np.zeros(lat * lng * 2))
+
+
+def cornell_box():  # primitives.cpp:133-190
+    h = f32(5.0)
+    fns = [[0, 0, 1], [0, 1, 0], [0, -1, 0], [1, 0, 0], [-1, 0, 0]]
+    v, n, t, uv, idx = _box_faces(fns, h, f32(-1.0), [0, h, 0])
+    mat = []
+    for i in range(5):
+        mat += [0 if i < 3 else i - 2] * 2
+    for fp in _FACE_POS:
+        v.append(np.array([fp[0], f32(2) * h - f32(0.01), fp[1]], dtype=f32))
+        n.append([0, -1, 0])
+        t.append([0, 0, 1, 1])
+        uv.append(fp)
+    idx += [20, 22, 21, 21, 22, 23]
+    mat += [3, 3]
+    return _make_mesh(v, n, t, uv, idx, mat)
+
+
+def cornell_materials():  # scene_explorer.cpp:52-67
+    return [
+        Material(name="cornell_base", base_color=(1, 1, 1, 1)),
+        Material(name="cornell_wall_l", base_color=(0.704, 0.016, 0.020, 1)),
+        Material(name="cornell_wall_r", base_color=(0.009, 0.591, 0.006, 1)),
+        Material(name="cornell_base", base_color=(0, 0, 0, 1), emission=(1, 1, 1), emission_strength=50.0),
+    ]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Scene container -> pt_scene_snapshot
+# ---------------------------------------------------------------------------------------------------------------
+@dataclass
+class Node:
+    mesh: int                    # index into Scene.meshes
+    world: np.ndarray            # 4x4 [col][row] world matrix (scene.cpp:527)
+    materials: list              # one Material per slot of the mesh
+
+
+@dataclass
+class Scene:
+    meshes: list = field(default_factory=list)
+    nodes: list = field(default_factory=list)
+    camera: Camera = field(default_factory=Camera)
+    camera_world: np.ndarray = field(default_factory=mat_identity)
+    name: str = "scene"
+
+    def add_mesh(self, mesh):
+        self.meshes.append(mesh)
+        return len(self.meshes) - 1
+
+    def add_instance(self, mesh_idx, transform, materials):
+        world = transform.matrix() if isinstance(transform, Transform) else np.asarray(transform, dtype=f32)
+        self.nodes.append(Node(mesh_idx, world, list(materials)))
+
+    def set_camera(self, camera, transform):
+        self.camera = camera
+        self.camera_world = transform.matrix() if isinstance(transform, Transform) else np.asarray(transform, dtype=f32)
+
+    @property
+    def triangle_count(self):
+        return sum(self.meshes[n.mesh].triangle_count for n in self.nodes)
+
+    def snapshot(self):
+        """Build the ctypes pt_scene_snapshot. The returned object keeps every buffer alive."""
+        return Snapshot(self)
+
+
+class Snapshot:
+    def __init__(self, scene):
+        self._keep = []
+        nm, ni = len(scene.meshes), len(scene.nodes)
+        self.meshes = (abi.Mesh * nm)()
+        for k, m in enumerate(scene.meshes):
+            arrs = [np.ascontiguousarray(m.positions, dtype=f32), np.ascontiguousarray(m.vertex_data, dtype=f32),
+                    np.ascontiguousarray(m.indices, dtype=np.uint32), np.ascontiguousarray(m.material_slots, dtype=np.uint32)]
+            self._keep += arrs
+            self.meshes[k].positions = arrs[0].ctypes.data
+            self.meshes[k].vertex_data = arrs[1].ctypes.data
+            self.meshes[k].indices = arrs[2].ctypes.data
+            self.meshes[k].material_slots = arrs[3].ctypes.data
+            self.meshes[k].vertex_count = len(arrs[0])
+            self.meshes[k].triangle_count = len(arrs[2]) // 3
+        self.instances = (abi.Instance * ni)()
+        self.instance_materials = (abi.InstanceMaterials * ni)()
+        for k, n in enumerate(scene.nodes):
+            for c in range(4):
+                for r in range(3):
+                    self.instances[k].transform[c][r] = n.world[c][r]
+            self.instances[k].options = 0
+            self.instances[k].mask = 0xFF
+            self.instances[k].intersectionFunctionTableOffset = 0
+            self.instances[k].accelerationStructureIndex = n.mesh
+            mats = (abi.MaterialGPU * len(n.materials))(*[m.to_gpu() for m in n.materials])
+            self._keep.append(mats)
+            self.instance_materials[k].materials = C.addressof(mats)
+            self.instance_materials[k].material_count = len(n.materials)
+        self.struct = abi.SceneSnapshot()
+        self.struct.meshes = C.addressof(self.meshes)
+        self.struct.mesh_count = nm
+        self.struct.instance_count = ni
+        self.struct.instances = C.addressof(self.instances)
+        self.struct.instance_materials = C.addressof(self.instance_materials)
+        cam = self.struct.camera
+        for c in range(4):
+            for r in range(4):
+                cam.world[c][r] = scene.camera_world[c][r]
+        cam.sensor_size[0], cam.sensor_size[1] = scene.camera.sensor_size
+        cam.focal_length = scene.camera.focal_length
+        cam.aperture = scene.camera.aperture
+        cam.aperture_blades = scene.camera.aperture_blades
+        cam.roundness = scene.camera.roundness
+        cam.bokeh_power = scene.camera.bokeh_power
+        cam.focus_distance = scene.camera.focus_distance
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs (all procedural; integer-hash seeded; no external files)
+# ---------------------------------------------------------------------------------------------------------------
+def _pcg4d(v):
+    """samplers.metal:16-23 on a python tuple of 4 u32 (used to seed procedural scenes)."""
+    M = 0xFFFFFFFF
+    x, y, z, w = [(a * 1664525 + 1013904223) & M for a in v]
+    x = (x + y * w) & M; y = (y + z * x) & M; z = (z + x * y) & M; w = (w + y * z) & M
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16
+    x = (x + y * w) & M; y = (y + z * x) & M; z = (z + x * y) & M; w = (w + y * z) & M
+    return x, y, z, w
+
+
+def cornell_scene(camera="bench"):
+    """C1: the Cornell box of scene_explorer.cpp:50-73.
+    camera="default": the reference's Camera menu entry (translation (-5,5,5), track origin, f=28mm)
+    (scene_explorer.cpp:84-90) — it sits outside the open +z face, off to the side.
+    camera="bench":   (0,5,15) looking at (0,5,0), the framing stated in BASELINE.md §3."""
+    sc = Scene(name="cornell")
+    box = sc.add_mesh(cornell_box())
+    sc.add_instance(box, Transform(), cornell_materials())
+    if camera == "default":
+        sc.set_camera(Camera.with_focal_length(28.0), Transform(translation=(-5, 5, 5), track=True))
+    else:
+        sc.set_camera(Camera.with_focal_length(28.0), Transform(translation=(0, 5, 15), target=(0, 5, 0), track=True))
+    return sc
+
+
+def cornell_sphere_scene(transmission=1.0, roughness=0.3):
+    """C2: Cornell box + one GGX dielectric object.  Suzanne is not in the reference tree; the stand-in is the
+    reference's own sphere primitive, primitives::sphere(1, 48, 64) = 6144 triangles (scene_explorer.cpp:46-47),
+    scaled x2 and resting on the floor; roughness 0.3, ior 1.5."""
+    sc = cornell_scene("bench")
+    sc.name = "cornell_sphere"
+    sph = sc.add_mesh(sphere(1.0, 48, 64))
+    sc.add_instance(sph, Transform(translation=(0.5, 2.0, 0.0), scale=(2, 2, 2)),
+                    [Material(name="glass", base_color=(1, 1, 1, 1), roughness=roughness, ior=1.5, transmission=transmission)])
+    return sc
+
+
+def field_scene(grid=32):
+    """C3/C4: the 1.04 M-triangle instanced mesh field: sphere(0.25, 22, 23) = 1012 triangles x grid^2 instances
+    on a 64x64 floor inside a Cornell shell enlarged x6.4; per-instance material from pcg4d(i,0,0,0)."""
+    sc = Scene(name=f"field{grid}")
+    shell = sc.add_mesh(cornell_box())
+    sc.add_instance(shell, Transform(scale=(6.4, 6.4, 6.4)), cornell_materials())
+    ball = sc.add_mesh(sphere(0.25, 22, 23))
+    span = 64.0
+    step = span / grid
+    for i in range(grid * grid):
+        gx, gz = i % grid, i // grid
+        h = _pcg4d((i, 0, 0, 0))
+        u = [(c >> 8) / float(1 << 24) for c in h]
+        kind = h[3] % 8
+        color = (0.25 + 0.7 * u[0], 0.25 + 0.7 * u[1], 0.25 + 0.7 * u[2], 1.0)
+        if kind < 4:
+            mat = Material(base_color=color, roughness=1.0)
+        elif kind < 6:
+            mat = Material(base_color=color, roughness=0.15 + 0.5 * u[0], metallic=1.0)
+        elif kind == 6:
+            mat = Material(base_color=color, roughness=0.25, ior=1.5)
+        else:
+            mat = Material(base_color=(1, 1, 1, 1), roughness=0.2, ior=1.5, transmission=1.0)
+        s = 2.0 + 1.5 * u[1]                      # radius 0.5 .. 0.875
+        x = -span / 2 + (gx + 0.5) * step
+        z = -span / 2 + (gz + 0.5) * step
+        y = 0.25 * s + 3.0 * u[2] * (1 if kind >= 4 else 0)
+        sc.add_instance(ball, Transform(translation=(x, y, z), scale=(s, s, s)), [mat])
+    sc.set_camera(Camera.with_focal_length(28.0), Transform(translation=(0, 14, 31.5), target=(0, 2, 0), track=True))
+    return sc
+
+
+CONFIGS = {
+    # name: (scene factory, width, height, spp, bounces)
+    "c1": (lambda: cornell_scene("bench"), 512, 512, 64, 4),
+    "c2": (cornell_sphere_scene, 1920, 1080, 256, 8),
+    "c3": (field_scene, 1920, 1080, 256, 8),
+}
