@@ -1,0 +1,239 @@
+// host_scene.h — host-side, once-per-render table building used by the HIP driver (renderer.hip): flattening of
+// the snapshot and the reference's CPU-side derivations, restated in fp32 with a fixed operation order.
+//   rebuildResourceBuffers   renderer_pt.cpp:448-651   (per-mesh / per-instance tables, MaterialGPU flags)
+//   updateConstants          renderer_pt.cpp:965-1021  (camera frame, idt)
+//   rebuildLightData         renderer_pt.cpp:838-917   (area-light table, cumulative power)
+// Plain C++ (no HIP) so the tests/emu debugging harness can build it for the host.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pt_device.h"
+
+namespace pt {
+
+struct HostScene {
+  std::vector<pt_float3> positions;
+  std::vector<pt_vertex_data> vdata;
+  std::vector<uint32_t> indices, slots;
+  std::vector<MeshInfo> meshes;
+  std::vector<InstanceInfo> instances;
+  std::vector<pt_material_gpu> materials;
+  std::vector<pt_area_light> lights;
+  pt_constants constants{};
+  Mat3 idt{};
+  uint32_t tri_count = 0;
+};
+
+inline int hs_fail(std::string* err, int code, const char* msg) {
+  if (err) *err = msg;
+  return code;
+}
+
+struct M3d { double m[3][3]; };  // [col][row]
+inline M3d m3_mul(const M3d& a, const M3d& b) {
+  M3d r{};
+  for (int c = 0; c < 3; c++)
+    for (int rr = 0; rr < 3; rr++) {
+      double s = 0;
+      for (int k = 0; k < 3; k++) s += a.m[k][rr] * b.m[c][k];
+      r.m[c][rr] = s;
+    }
+  return r;
+}
+inline M3d m3_inv(const M3d& a) {
+  const double(*m)[3] = a.m;
+  const double c00 = m[1][1] * m[2][2] - m[2][1] * m[1][2];
+  const double c01 = m[2][1] * m[0][2] - m[0][1] * m[2][2];
+  const double c02 = m[0][1] * m[1][2] - m[1][1] * m[0][2];
+  const double id = 1.0 / (m[0][0] * c00 + m[1][0] * c01 + m[2][0] * c02);
+  M3d r{};
+  r.m[0][0] = c00 * id; r.m[0][1] = c01 * id; r.m[0][2] = c02 * id;
+  r.m[1][0] = (m[2][0] * m[1][2] - m[1][0] * m[2][2]) * id;
+  r.m[1][1] = (m[0][0] * m[2][2] - m[2][0] * m[0][2]) * id;
+  r.m[1][2] = (m[1][0] * m[0][2] - m[0][0] * m[1][2]) * id;
+  r.m[2][0] = (m[1][0] * m[2][1] - m[2][0] * m[1][1]) * id;
+  r.m[2][1] = (m[2][0] * m[0][1] - m[0][0] * m[2][1]) * id;
+  r.m[2][2] = (m[0][0] * m[1][1] - m[1][0] * m[0][1]) * id;
+  return r;
+}
+// core/colorspace.cpp:13-33: primaries + white point -> RGB->XYZ. Evaluated in double, rounded once (Apple's
+// simd::inverse is closed, so the last bit of `idt` is unpinned either way).
+inline M3d colorspace_to_xyz(const float r[2], const float g[2], const float b[2], const float w[2]) {
+  const double prim[3][3] = {{r[0], r[1], 1.0 - (double)r[0] - (double)r[1]},
+                             {g[0], g[1], 1.0 - (double)g[0] - (double)g[1]},
+                             {b[0], b[1], 1.0 - (double)b[0] - (double)b[1]}};
+  const double wx = w[0], wy = w[1], wz = 1.0 - wx - wy;
+  const double W[3] = {wx / wy, 1.0, wz / wy};
+  M3d mx{};
+  for (int c = 0; c < 3; c++)
+    for (int rr = 0; rr < 3; rr++) mx.m[c][rr] = prim[c][rr];
+  const M3d inv = m3_inv(mx);
+  double scale[3];
+  for (int rr = 0; rr < 3; rr++) scale[rr] = inv.m[0][rr] * W[0] + inv.m[1][rr] * W[1] + inv.m[2][rr] * W[2];
+  M3d out{};
+  for (int c = 0; c < 3; c++)
+    for (int rr = 0; rr < 3; rr++) out.m[c][rr] = mx.m[c][rr] * scale[c];
+  return out;
+}
+// color::transform(BT709, working) (colorspace.hpp:61-63; renderer_pt.cpp:895, 1000-1002)
+inline Mat3 compute_idt(const pt_colorspace& ws) {
+  const float r709[2] = {0.640f, 0.330f}, g709[2] = {0.300f, 0.600f}, b709[2] = {0.150f, 0.060f}, d65[2] = {0.3127f, 0.3290f};
+  const M3d src = colorspace_to_xyz(r709, g709, b709, d65);
+  const M3d dst = colorspace_to_xyz(ws.r, ws.g, ws.b, ws.w);
+  const M3d t = m3_mul(m3_inv(dst), src);
+  Mat3 o;
+  o.c0 = v3((float)t.m[0][0], (float)t.m[0][1], (float)t.m[0][2]);
+  o.c1 = v3((float)t.m[1][0], (float)t.m[1][1], (float)t.m[1][2]);
+  o.c2 = v3((float)t.m[2][0], (float)t.m[2][1], (float)t.m[2][2]);
+  return o;
+}
+inline pt_float3 to_pt(vec3 v) { return {v.x, v.y, v.z, 0.0f}; }
+inline vec3 from_pt(const pt_float3& v) { return v3(v.x, v.y, v.z); }
+
+
+inline int build_host_scene(const pt_scene_snapshot* scene, const pt_render_params* p, uint32_t lut_w_E, uint32_t lut_w_Eavg,
+                            HostScene* out, std::string* err) {
+  // ---- flatten the snapshot (rebuildResourceBuffers, renderer_pt.cpp:448-651) ----
+  std::vector<MeshInfo>& meshes = out->meshes;
+  meshes.assign(scene->mesh_count, MeshInfo{});
+  size_t nv = 0, nt = 0;
+  for (uint32_t m = 0; m < scene->mesh_count; m++) {
+    const pt_mesh& pm = scene->meshes[m];
+    if (pm.vertex_count && (!pm.positions || !pm.vertex_data)) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "mesh: null vertex arrays");
+    if (pm.triangle_count && (!pm.indices || !pm.material_slots)) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "mesh: null index arrays");
+    meshes[m] = {(uint32_t)nv, (uint32_t)nt, pm.triangle_count, 0};
+    nv += pm.vertex_count;
+    nt += pm.triangle_count;
+  }
+  if (nv >= (1ull << 31) || nt >= (1ull << 30)) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "scene too large for 32-bit indices");
+  std::vector<pt_float3>& positions = out->positions;
+  std::vector<pt_vertex_data>& vdata = out->vdata;
+  std::vector<uint32_t>&indices = out->indices, &slots = out->slots;
+  positions.resize(nv); vdata.resize(nv); indices.resize(3 * nt); slots.resize(nt);
+  for (uint32_t m = 0; m < scene->mesh_count; m++) {
+    const pt_mesh& pm = scene->meshes[m];
+    if (pm.vertex_count) {
+      memcpy(&positions[meshes[m].vertex_base], pm.positions, sizeof(pt_float3) * pm.vertex_count);
+      memcpy(&vdata[meshes[m].vertex_base], pm.vertex_data, sizeof(pt_vertex_data) * pm.vertex_count);
+    }
+    if (pm.triangle_count) {
+      memcpy(&indices[3 * (size_t)meshes[m].tri_base], pm.indices, sizeof(uint32_t) * 3 * pm.triangle_count);
+      memcpy(&slots[meshes[m].tri_base], pm.material_slots, sizeof(uint32_t) * pm.triangle_count);
+      for (size_t k = 0; k < 3 * (size_t)pm.triangle_count; k++)
+        if (pm.indices[k] >= pm.vertex_count) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "mesh: vertex index out of range");
+    }
+  }
+  std::vector<InstanceInfo>& instances = out->instances;
+  instances.assign(scene->instance_count, InstanceInfo{});
+  std::vector<pt_material_gpu>& materials = out->materials;
+  materials.clear();
+  uint64_t tri_total = 0;
+  for (uint32_t i = 0; i < scene->instance_count; i++) {
+    const pt_instance& in = scene->instances[i];
+    if (in.accelerationStructureIndex >= scene->mesh_count) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "instance: mesh index out of range");
+    const pt_instance_materials& im = scene->instance_materials[i];
+    if (im.material_count && !im.materials) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "instance: null material array");
+    InstanceInfo ii{};
+    for (int k = 0; k < 3; k++) { ii.c0[k] = in.transform[0][k]; ii.c1[k] = in.transform[1][k]; ii.c2[k] = in.transform[2][k]; ii.c3[k] = in.transform[3][k]; }
+    ii.mesh = in.accelerationStructureIndex;
+    ii.material_base = (uint32_t)materials.size();
+    ii.tri_global_base = (uint32_t)tri_total;
+    instances[i] = ii;
+    const pt_mesh& pm = scene->meshes[ii.mesh];
+    for (uint32_t t = 0; t < pm.triangle_count; t++)
+      if (pm.material_slots[t] >= im.material_count) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "instance: material slot out of range");
+    for (uint32_t k = 0; k < im.material_count; k++) {
+      pt_material_gpu mat = im.materials[k];
+      if (mat.baseTextureId >= 0 || mat.rmTextureId >= 0 || mat.transmissionTextureId >= 0 || mat.clearcoatTextureId >= 0 ||
+          mat.emissionTextureId >= 0 || mat.normalTextureId >= 0)
+        return hs_fail(err, PT_ERR_UNSUPPORTED, "textures (SURVEY §8f N3) are not part of this ABI version: texture ids must be -1");
+      // renderer_pt.cpp:626-633: the Renderer derives these two flags when it fills MaterialGPU
+      const vec3 e = from_pt(mat.emission) * mat.emissionStrength;
+      if (length_squared(e) > 0.0f) mat.flags |= PT_MATERIAL_EMISSIVE;
+      if (mat.anisotropy != 0.0f) mat.flags |= PT_MATERIAL_ANISOTROPIC;
+      materials.push_back(mat);
+    }
+    tri_total += pm.triangle_count;
+  }
+  if (tri_total >= (1ull << 31)) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "too many flattened triangles");
+  out->tri_count = (uint32_t)tri_total;
+
+  // ---- constants (updateConstants, renderer_pt.cpp:965-1021) ----
+  const Mat3 idt = compute_idt(p->working_space);
+  out->idt = idt;
+  const pt_camera& cam = scene->camera;
+  pt_constants& C = out->constants;
+  memset(&C, 0, sizeof(C));
+  {
+    vec3 col[4];
+    for (int i = 0; i < 4; i++) col[i] = v3(cam.world[i][0], cam.world[i][1], cam.world[i][2]);
+    const vec3 u = col[0] / length(col[0]);  // "rescale the camera transform to ignore any scaling" (:970-976)
+    const vec3 v = col[1] / length(col[1]);
+    const vec3 w = col[2] / length(col[2]);
+    const vec3 pos = col[3];
+    const float sx = (float)p->width, sy = (float)p->height;
+    const float aspect = sx / sy;
+    const float sensorAspect = cam.sensor_size[0] / cam.sensor_size[1];
+    const float cropped = cam.sensor_size[0] / fmaxf(sensorAspect, aspect);  // camera.hpp:47-50
+    const float vh = cam.focus_distance * cropped / cam.focal_length;
+    const float vw = vh * aspect;
+    const vec3 vu = u * vw;
+    const vec3 vv = -v * vh;
+    C.spp = p->spp;
+    C.gmonBuckets = 1;
+    C.lutSizeE = lut_w_E;
+    C.lutSizeEavg = lut_w_Eavg;
+    C.flags = p->flags;
+    C.size[0] = p->width;
+    C.size[1] = p->height;
+    C.idt[0] = to_pt(idt.c0); C.idt[1] = to_pt(idt.c1); C.idt[2] = to_pt(idt.c2);
+    C.camera.position = to_pt(pos);
+    C.camera.topLeft = to_pt((pos - cam.focus_distance * w) - (vu + vv) * 0.5f);
+    C.camera.pixelDeltaU = to_pt(vu / sx);
+    C.camera.pixelDeltaV = to_pt(vv / sy);
+    C.camera.apertureRadius = cam.aperture > 0.0f ? (cam.focal_length / 2000.0f) / cam.aperture : 0.0f;
+    C.camera.apertureBlades = cam.aperture_blades;
+    C.camera.apertureRoundness = cam.roundness;
+    C.camera.bokehPower = cam.bokeh_power;
+  }
+
+  // ---- area lights (rebuildLightData, renderer_pt.cpp:838-917) ----
+  out->lights.clear();
+  float totalPower = 0.0f;
+  for (uint32_t i = 0; i < scene->instance_count; i++) {
+    const InstanceInfo& ii = instances[i];
+    const pt_mesh& pm = scene->meshes[ii.mesh];
+    const pt_instance_materials& im = scene->instance_materials[i];
+    bool any = false;
+    for (uint32_t k = 0; k < im.material_count; k++) any = any || (materials[ii.material_base + k].flags & PT_MATERIAL_EMISSIVE);
+    if (!any) continue;
+    const vec3 c0 = v3(ii.c0[0], ii.c0[1], ii.c0[2]), c1 = v3(ii.c1[0], ii.c1[1], ii.c1[2]);
+    const vec3 c2 = v3(ii.c2[0], ii.c2[1], ii.c2[2]), c3 = v3(ii.c3[0], ii.c3[1], ii.c3[2]);
+    auto xf = [&](const pt_float3& q) { return ((c0 * q.x + c1 * q.y) + c2 * q.z) + c3; };
+    for (uint32_t t = 0; t < pm.triangle_count; t++) {
+      const pt_material_gpu& mat = materials[ii.material_base + pm.material_slots[t]];
+      if (!(mat.flags & PT_MATERIAL_EMISSIVE)) continue;
+      const uint32_t i0 = pm.indices[3 * t], i1 = pm.indices[3 * t + 1], i2 = pm.indices[3 * t + 2];
+      const vec3 v0 = xf(pm.positions[i0]), v1 = xf(pm.positions[i1]), v2 = xf(pm.positions[i2]);
+      const float area = length(cross(v1 - v0, v2 - v0)) * 0.5f;
+      const vec3 emission = mul(idt, from_pt(mat.emission)) * mat.emissionStrength;
+      const float power = emission.y * area * kPi;  // dot(emission, (0,1,0)) * area * pi
+      totalPower += power;
+      pt_area_light L{};
+      L.instanceIdx = i; L.indices[0] = i0; L.indices[1] = i1; L.indices[2] = i2;
+      L.area = area; L.power = power; L.cumulativePower = totalPower; L.emission = to_pt(emission);
+      out->lights.push_back(L);
+    }
+  }
+  C.lightCount = (uint32_t)out->lights.size();
+  C.envLightCount = 0;
+  C.totalLightPower = totalPower;
+
+  return PT_OK;
+}
+
+}  // namespace pt

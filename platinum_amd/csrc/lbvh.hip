@@ -1,0 +1,311 @@
+// lbvh.hip — GPU LBVH build: replaces Metal's closed acceleration-structure build
+// (renderer_pt.cpp:244-294 makeAccelStruct, :653-749 rebuildAccelerationStructures).
+//
+//   k_flatten   instance x primitive -> world-space TriRec + AABB (fp32 transformPoint, the intersection contract)
+//   k_bounds    scene centroid bounds (wave reduce + ordered-int atomics)
+//   k_morton    63-bit Morton code of the AABB centre (21 bits / axis, cubic cells)
+//   radix sort  rocPRIM (hipcub::DeviceRadixSort::SortPairs, 64-bit keys)
+//   k_karras    Karras 2012 radix tree: one thread per internal node, duplicate codes split by position
+//   k_refit     bottom-up AABB union, second arrival at a node proceeds (agent-scope fences around the counter)
+//   k_emit      64-byte traversal nodes with both (inflated) child boxes inline + triangles in leaf order
+//
+// Not on the per-sample hot path: runs once per pt_start_render; timed separately (pt_stats.bvh_build_ms).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "kernels.h"
+#include "pt_shade.h"
+
+namespace pt {
+
+namespace {
+
+struct alignas(16) Box { float lo[3]; float hi[3]; float _pad[2]; };
+
+__device__ __forceinline__ int float_to_ordered(float f) {
+  int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ordered_to_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__global__ void __launch_bounds__(256) k_flatten(DeviceScene S, uint32_t instance_count, uint32_t tri_count,
+                                                  TriRec* __restrict__ tris, Box* __restrict__ boxes) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= tri_count) return;
+  // instance = last i with tri_global_base <= g
+  uint32_t lo = 0, hi = instance_count;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (S.instances[mid].tri_global_base <= g) lo = mid; else hi = mid;
+  }
+  const InstanceInfo inst = S.instances[lo];
+  const MeshInfo mesh = S.meshes[inst.mesh];
+  const uint32_t prim = g - inst.tri_global_base;
+  const uint32_t* idx = &S.indices[3 * (size_t)(mesh.tri_base + prim)];
+  const Xform X = load_xform(inst);
+  const vec3 v0 = transformPoint(ld3(S.positions[mesh.vertex_base + idx[0]]), X);
+  const vec3 v1 = transformPoint(ld3(S.positions[mesh.vertex_base + idx[1]]), X);
+  const vec3 v2 = transformPoint(ld3(S.positions[mesh.vertex_base + idx[2]]), X);
+  const vec3 e1 = v1 - v0, e2 = v2 - v0;
+  TriRec t;
+  t.v0[0] = v0.x; t.v0[1] = v0.y; t.v0[2] = v0.z;
+  t.e1[0] = e1.x; t.e1[1] = e1.y; t.e1[2] = e1.z;
+  t.e2[0] = e2.x; t.e2[1] = e2.y; t.e2[2] = e2.z;
+  t.inst = lo; t.prim = prim; t.gid = g;
+  tris[g] = t;
+  Box b;
+  b.lo[0] = fminf(v0.x, fminf(v1.x, v2.x)); b.hi[0] = fmaxf(v0.x, fmaxf(v1.x, v2.x));
+  b.lo[1] = fminf(v0.y, fminf(v1.y, v2.y)); b.hi[1] = fmaxf(v0.y, fmaxf(v1.y, v2.y));
+  b.lo[2] = fminf(v0.z, fminf(v1.z, v2.z)); b.hi[2] = fmaxf(v0.z, fmaxf(v1.z, v2.z));
+  b._pad[0] = b._pad[1] = 0.0f;
+  boxes[g] = b;
+}
+
+__global__ void k_init_bounds(int* bounds) {
+  if (threadIdx.x < 3) bounds[threadIdx.x] = 0x7fffffff;
+  else if (threadIdx.x < 6) bounds[threadIdx.x] = (int)0x80000000;
+}
+
+__global__ void __launch_bounds__(256) k_bounds(const Box* __restrict__ boxes, uint32_t n, int* __restrict__ bounds) {
+  float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+  for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < n; g += gridDim.x * 256) {
+    const Box b = boxes[g];
+    for (int k = 0; k < 3; k++) {
+      const float c = 0.5f * (b.lo[k] + b.hi[k]);
+      lo[k] = fminf(lo[k], c);
+      hi[k] = fmaxf(hi[k], c);
+    }
+  }
+  for (int k = 0; k < 3; k++)
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+      hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+    }
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 3; k++) {
+      atomicMin(&bounds[k], float_to_ordered(lo[k]));
+      atomicMax(&bounds[3 + k], float_to_ordered(hi[k]));
+    }
+}
+
+__device__ __forceinline__ uint64_t expand21(uint64_t v) {  // spread 21 bits to every third bit
+  v &= 0x1fffffull;
+  v = (v | v << 32) & 0x1f00000000ffffull;
+  v = (v | v << 16) & 0x1f0000ff0000ffull;
+  v = (v | v << 8) & 0x100f00f00f00f00full;
+  v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+  v = (v | v << 2) & 0x1249249249249249ull;
+  return v;
+}
+
+__global__ void __launch_bounds__(256) k_morton(const Box* __restrict__ boxes, uint32_t n, const int* __restrict__ bounds,
+                                                 uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= n) return;
+  float lo[3], ext = 0.0f;
+  for (int k = 0; k < 3; k++) {
+    lo[k] = ordered_to_float(bounds[k]);
+    ext = fmaxf(ext, ordered_to_float(bounds[3 + k]) - lo[k]);
+  }
+  const float scale = ext > 0.0f ? 2097152.0f / ext : 0.0f;  // 2^21 cells along the longest axis
+  const Box b = boxes[g];
+  uint64_t code = 0;
+  for (int k = 0; k < 3; k++) {
+    const float c = 0.5f * (b.lo[k] + b.hi[k]);
+    float q = (c - lo[k]) * scale;
+    q = fminf(fmaxf(q, 0.0f), 2097151.0f);
+    code |= expand21((uint64_t)q) << (2 - k);  // x is the most significant of each triple
+  }
+  keys[g] = code;
+  vals[g] = g;
+}
+
+__device__ __forceinline__ int karras_delta(const uint64_t* __restrict__ keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint64_t x = keys[i] ^ keys[j];
+  if (x == 0) return 64 + __clz((uint32_t)(i ^ j));
+  return __clzll((long long)x);
+}
+
+// Internal node i covers a range of sorted leaves; children are encoded as refs (kLeafBit | leaf) or node index.
+__global__ void __launch_bounds__(256) k_karras(const uint64_t* __restrict__ keys, int n, uint2* __restrict__ children,
+                                                 uint32_t* __restrict__ parent_int, uint32_t* __restrict__ parent_leaf) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = (karras_delta(keys, n, i, i + 1) - karras_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = karras_delta(keys, n, i, i - d);
+  int lmax = 2;
+  while (karras_delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+  int l = 0;
+  for (int t = lmax / 2; t >= 1; t /= 2)
+    if (karras_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = karras_delta(keys, n, i, j);
+  int s = 0;
+  int t = l;
+  do {
+    t = (t + 1) >> 1;
+    if (karras_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+  } while (t > 1);
+  const int gamma = i + s * d + (d < 0 ? -1 : 0);
+  const int lo = i < j ? i : j, hi = i < j ? j : i;
+  uint32_t left, right;
+  if (lo == gamma) { left = kLeafBit | (uint32_t)gamma; parent_leaf[gamma] = (uint32_t)i; }
+  else { left = (uint32_t)gamma; parent_int[gamma] = (uint32_t)i; }
+  if (hi == gamma + 1) { right = kLeafBit | (uint32_t)(gamma + 1); parent_leaf[gamma + 1] = (uint32_t)i; }
+  else { right = (uint32_t)(gamma + 1); parent_int[gamma + 1] = (uint32_t)i; }
+  children[i] = make_uint2(left, right);
+  if (i == 0) parent_int[0] = kInvalidRef;
+}
+
+__device__ __forceinline__ Box load_child_box(uint32_t ref, const Box* __restrict__ leaf_boxes, const uint32_t* __restrict__ order,
+                                              const Box* node_boxes) {
+  if (ref & kLeafBit) return leaf_boxes[order[ref & ~kLeafBit]];
+  // written by another workgroup during this kernel: bypass the (non-coherent) vector L1
+  Box b;
+  const float* p = reinterpret_cast<const float*>(&node_boxes[ref]);
+  for (int k = 0; k < 3; k++) {
+    b.lo[k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b.hi[k] = __hip_atomic_load(p + 3 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return b;
+}
+
+__global__ void __launch_bounds__(256) k_refit(int n, const uint2* __restrict__ children, const uint32_t* __restrict__ parent_int,
+                                                const uint32_t* __restrict__ parent_leaf, const Box* __restrict__ leaf_boxes,
+                                                const uint32_t* __restrict__ order, Box* node_boxes, uint32_t* flags,
+                                                uint32_t* __restrict__ max_depth) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  // depth of this leaf (stats only)
+  {
+    uint32_t depth = 1, p = parent_leaf[j];
+    while (p != 0) { p = parent_int[p]; depth++; }
+    atomicMax(max_depth, depth);
+  }
+  uint32_t cur = parent_leaf[j];
+  for (;;) {
+    __threadfence();  // release: this thread's node_boxes store (if any) is visible before the arrival count
+    const uint32_t old = atomicAdd(&flags[cur], 1u);
+    if (old == 0) return;  // first arrival: the sibling subtree is not finished yet
+    __threadfence();       // acquire side of the hand-off
+    const uint2 ch = children[cur];
+    const Box a = load_child_box(ch.x, leaf_boxes, order, node_boxes);
+    const Box b = load_child_box(ch.y, leaf_boxes, order, node_boxes);
+    float* p = reinterpret_cast<float*>(&node_boxes[cur]);
+    for (int k = 0; k < 3; k++) {
+      __hip_atomic_store(p + k, fminf(a.lo[k], b.lo[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p + 3 + k, fmaxf(a.hi[k], b.hi[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (cur == 0) return;
+    cur = parent_int[cur];
+  }
+}
+
+// Conservative inflation: the traversal's slab test must never cull a triangle the Moeller-Trumbore test accepts
+// (intersection contract). 8e-6 relative is ~64 ulp of the coordinate magnitude.
+__device__ __forceinline__ void inflate_into(const Box& b, float lo[3], float hi[3]) {
+  for (int k = 0; k < 3; k++) {
+    const float m = fmaxf(fabsf(b.lo[k]), fabsf(b.hi[k]));
+    const float eps = m * 8e-6f + 1e-30f;
+    lo[k] = b.lo[k] - eps;
+    hi[k] = b.hi[k] + eps;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_emit(int n, const uint2* __restrict__ children, const Box* __restrict__ leaf_boxes,
+                                               const uint32_t* __restrict__ order, const Box* __restrict__ node_boxes,
+                                               const TriRec* __restrict__ tris_in, BvhNode* __restrict__ nodes,
+                                               TriRec* __restrict__ tris_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) tris_out[i] = tris_in[order[i]];
+  if (i >= n - 1) return;
+  const uint2 ch = children[i];
+  const Box a = (ch.x & kLeafBit) ? leaf_boxes[order[ch.x & ~kLeafBit]] : node_boxes[ch.x];
+  const Box b = (ch.y & kLeafBit) ? leaf_boxes[order[ch.y & ~kLeafBit]] : node_boxes[ch.y];
+  BvhNode nd;
+  inflate_into(a, nd.lo0, nd.hi0);
+  inflate_into(b, nd.lo1, nd.hi1);
+  nd.ref0 = ch.x;
+  nd.ref1 = ch.y;
+  nd._pad[0] = nd._pad[1] = 0;
+  nodes[i] = nd;
+}
+
+#define LB_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = e_; goto done; } } while (0)
+
+}  // namespace
+
+hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_count, uint32_t tri_count, LbvhResult* out) {
+  *out = LbvhResult{};
+  if (tri_count == 0) return hipSuccess;
+  hipError_t err = hipSuccess;
+  const uint32_t n = tri_count;
+  const uint32_t blocks = (n + 255) / 256;
+  TriRec* tris_tmp = nullptr; Box* leaf_boxes = nullptr; Box* node_boxes = nullptr;
+  uint64_t *keys_a = nullptr, *keys_b = nullptr; uint32_t *vals_a = nullptr, *vals_b = nullptr;
+  uint2* children = nullptr; uint32_t *parent_int = nullptr, *parent_leaf = nullptr, *flags = nullptr;
+  int* bounds = nullptr; uint32_t* max_depth = nullptr; void* sort_tmp = nullptr; size_t sort_bytes = 0;
+  uint32_t depth_h = 0;
+
+  LB_CHECK(hipMalloc(&tris_tmp, sizeof(TriRec) * (size_t)n));
+  LB_CHECK(hipMalloc(&out->tris, sizeof(TriRec) * (size_t)n));
+  LB_CHECK(hipMalloc(&leaf_boxes, sizeof(Box) * (size_t)n));
+  LB_CHECK(hipMalloc(&bounds, sizeof(int) * 8));
+  LB_CHECK(hipMalloc(&max_depth, sizeof(uint32_t)));
+  LB_CHECK(hipMemsetAsync(max_depth, 0, sizeof(uint32_t), s));
+  hipLaunchKernelGGL(k_flatten, dim3(blocks), dim3(256), 0, s, S, instance_count, n, tris_tmp, leaf_boxes);
+
+  if (n == 1) {
+    LB_CHECK(hipMemcpyAsync(out->tris, tris_tmp, sizeof(TriRec), hipMemcpyDeviceToDevice, s));
+    out->root_ref = kLeafBit | 0u;
+    out->node_count = 0;
+    out->max_depth = 1;
+    LB_CHECK(hipStreamSynchronize(s));
+    goto done;
+  }
+
+  LB_CHECK(hipMalloc(&keys_a, sizeof(uint64_t) * (size_t)n));
+  LB_CHECK(hipMalloc(&keys_b, sizeof(uint64_t) * (size_t)n));
+  LB_CHECK(hipMalloc(&vals_a, sizeof(uint32_t) * (size_t)n));
+  LB_CHECK(hipMalloc(&vals_b, sizeof(uint32_t) * (size_t)n));
+  LB_CHECK(hipMalloc(&children, sizeof(uint2) * (size_t)(n - 1)));
+  LB_CHECK(hipMalloc(&parent_int, sizeof(uint32_t) * (size_t)(n - 1)));
+  LB_CHECK(hipMalloc(&parent_leaf, sizeof(uint32_t) * (size_t)n));
+  LB_CHECK(hipMalloc(&flags, sizeof(uint32_t) * (size_t)(n - 1)));
+  LB_CHECK(hipMalloc(&node_boxes, sizeof(Box) * (size_t)(n - 1)));
+  LB_CHECK(hipMalloc(&out->nodes, sizeof(BvhNode) * (size_t)(n - 1)));
+  LB_CHECK(hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)(n - 1), s));
+
+  hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, s, bounds);
+  hipLaunchKernelGGL(k_bounds, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, s, leaf_boxes, n, bounds);
+  hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, s, leaf_boxes, n, bounds, keys_a, vals_a);
+
+  LB_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 63, s));
+  LB_CHECK(hipMalloc(&sort_tmp, sort_bytes));
+  LB_CHECK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 63, s));
+
+  hipLaunchKernelGGL(k_karras, dim3(blocks), dim3(256), 0, s, keys_b, (int)n, children, parent_int, parent_leaf);
+  hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, s, (int)n, children, parent_int, parent_leaf, leaf_boxes, vals_b,
+                     node_boxes, flags, max_depth);
+  hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, s, (int)n, children, leaf_boxes, vals_b, node_boxes, tris_tmp,
+                     out->nodes, out->tris);
+  LB_CHECK(hipGetLastError());
+  LB_CHECK(hipMemcpyAsync(&depth_h, max_depth, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  LB_CHECK(hipStreamSynchronize(s));
+  out->root_ref = 0;
+  out->node_count = n - 1;
+  out->max_depth = depth_h;
+
+done:
+  (void)hipFree(tris_tmp); (void)hipFree(leaf_boxes); (void)hipFree(node_boxes); (void)hipFree(keys_a); (void)hipFree(keys_b); (void)hipFree(vals_a);
+  (void)hipFree(vals_b); (void)hipFree(children); (void)hipFree(parent_int); (void)hipFree(parent_leaf); (void)hipFree(flags); (void)hipFree(bounds);
+  (void)hipFree(max_depth); (void)hipFree(sort_tmp);
+  if (err != hipSuccess) {
+    (void)hipFree(out->nodes); (void)hipFree(out->tris);
+    *out = LbvhResult{};
+  }
+  return err;
+}
+
+}  // namespace pt

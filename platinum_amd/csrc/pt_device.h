@@ -1,0 +1,131 @@
+// pt_device.h — HBM data layout of the wavefront path tracer (see DESIGN.md "Data layout in HBM").
+//
+// Scene tables keep the reference's record layouts (pt_shader_defs.hpp, core/mesh.hpp) so the snapshot is
+// uploaded by plain memcpy; what the reference reaches through per-mesh / per-instance pointer tables
+// (VertexResource / PrimitiveResource / InstanceResource, pt_shader_defs.hpp:117-128) is reached here through
+// base offsets into concatenated arrays.
+#pragma once
+#include "../../include/ptamd.h"
+#include "pt_math.h"
+
+namespace pt {
+
+// ---- geometry tables ------------------------------------------------------------------------------------------
+struct MeshInfo {          // replaces VertexResource + PrimitiveResource for one mesh
+  uint32_t vertex_base;    // into positions[] / vdata[]
+  uint32_t tri_base;       // into indices[] (x3) / slots[]
+  uint32_t tri_count;
+  uint32_t _pad;
+};
+
+struct alignas(16) InstanceInfo {  // MTLAccelerationStructureInstanceDescriptor + InstanceResource, 64 B
+  float c0[3], c1[3], c2[3], c3[3];  // object->world, four packed columns (renderer_pt.cpp:706-716)
+  uint32_t mesh;                     // accelerationStructureIndex
+  uint32_t material_base;            // into materials[]: this instance's MaterialGPU array
+  uint32_t tri_global_base;          // global id of this instance's first flattened triangle
+  uint32_t _pad;
+};
+static_assert(sizeof(InstanceInfo) == 64, "InstanceInfo");
+
+// ---- BVH -------------------------------------------------------------------------------------------------------
+// World-space triangle record in BVH leaf order, 48 B = 3 x dwordx4.
+struct alignas(16) TriRec {
+  float v0[3];
+  float e1[3];
+  float e2[3];
+  uint32_t inst;   // instance id
+  uint32_t prim;   // primitive id inside the instance's mesh
+  uint32_t gid;    // global id = InstanceInfo.tri_global_base + prim : the closest-hit tie-break key
+};
+static_assert(sizeof(TriRec) == 48, "TriRec");
+
+// BVH2 node with both child boxes inline, 64 B = 4 x dwordx4 (one 64-B half of an L2 line).
+// ref: bit31 set = leaf, low bits = index into tris[]; else index of an internal node.
+struct alignas(16) BvhNode {
+  float lo0[3], hi0[3];
+  float lo1[3], hi1[3];
+  uint32_t ref0, ref1;
+  uint32_t _pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode");
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kInvalidRef = 0xffffffffu;
+
+// ---- sampler table: one entry per Halton dimension (defs.metal:115-194 holds the 620 primes) ---------------------
+struct alignas(16) HaltonEntry {
+  uint32_t prime;
+  uint32_t magic_hi, magic_lo;  // M = floor((2^64-1)/prime) + 1 ; q = (M * n) >> 64 is exact for 32-bit n
+  float inv;                    // 1.0f / (float)prime
+};
+constexpr int kHaltonDims = 620;
+
+// ---- LUTs (pt_shader_defs.hpp:130-139) -----------------------------------------------------------------------
+struct Lut { const float* d; int w, h, depth; };
+struct LutSet { Lut E, Eavg, EMs, EavgMs, ETransIn, ETransOut; };  // the two *avgTrans tables are never sampled
+
+struct Mat3 { vec3 c0, c1, c2; };
+PT_HD vec3 mul(const Mat3& m, vec3 v) { return (m.c0 * v.x + m.c1 * v.y) + m.c2 * v.z; }
+
+// Everything a kernel needs to know about the scene; passed by value as a kernel argument (constant/SGPR space).
+struct DeviceScene {
+  const pt_float3* positions;
+  const pt_vertex_data* vdata;
+  const uint32_t* indices;
+  const uint32_t* slots;
+  const MeshInfo* meshes;
+  const InstanceInfo* instances;
+  const pt_material_gpu* materials;
+  const pt_area_light* lights;
+  const BvhNode* nodes;
+  const TriRec* tris;
+  uint32_t tri_count;
+  uint32_t root_ref;       // kLeafBit|0 for a single-triangle scene, 0 otherwise, kInvalidRef when empty
+  const HaltonEntry* halton;
+  LutSet luts;
+  // Constants (pt_shader_defs.hpp:105-115) — the fields the kernels read
+  pt_camera_data camera;
+  Mat3 idt;
+  uint32_t width, height;
+  uint32_t lightCount;
+  float totalLightPower;
+  int32_t flags;            // RendererFlags
+  uint32_t integrator;      // PT_INTEGRATOR_*
+  uint32_t max_bounces;
+};
+
+// ---- wavefront state (SoA, one element per path slot; ping-pong between bounces) ---------------------------------
+// rayO.w  = pdf of the BSDF sample that generated this ray (lastSample.pdf, kernel.metal:574)
+// rayD.w  = bits: [9:0] next Halton dimension, [10] lastSample was specular (kernel.metal:561)
+// att.w   = bits: Halton offset of this (pixel, sample) (samplers.metal:154-156)
+struct PathState {
+  vec4* rayO;
+  vec4* rayD;
+  vec4* att;
+  uint32_t* pid;   // sample_slot * W*H + pixel : index into the per-sample radiance buffer
+};
+constexpr uint32_t kMetaDimMask = 0x3ffu;
+constexpr uint32_t kMetaSpecular = 1u << 10;
+
+struct ShadowQueue {
+  vec4* o;        // origin.xyz, tmax
+  vec4* d;        // direction.xyz, bits(pid)
+  vec4* contrib;  // attenuation * Ld (kernel.metal:631-637), added to the path's radiance if unoccluded
+};
+
+// Per-batch device counters (zeroed by one memset per batch).
+struct BatchCounters {
+  uint32_t active[64];    // active[b]  = live paths entering bounce b          (b <= 50)
+  uint32_t shadow[64];    // shadow[b]  = shadow rays queued at bounce b
+  uint32_t work[192];     // dynamic-fetch cursors: [3*b + {0 closest, 1 shade, 2 shadow}]
+  uint32_t shaded;        // hits shaded
+  uint32_t _pad[3];
+  unsigned long long nodes_closest, tris_closest, nodes_shadow, tris_shadow;  // instrumented runs only
+};
+
+struct Totals {  // running totals since pt_start_render (folded from BatchCounters after each batch)
+  unsigned long long closest_rays, shadow_rays, shaded_hits, paths;
+  unsigned long long nodes_closest, tris_closest, nodes_shadow, tris_shadow;
+  unsigned long long counted_closest, counted_shadow;
+};
+
+}  // namespace pt

@@ -1,0 +1,85 @@
+// pt_sampler.h — the reference's sample streams on the device.
+//   pcg4d                     samplers.metal:16-23
+//   HaltonSampler             samplers.metal:154-184 (ctor, sample1d, sample2d, halton)
+//   sampleDisk / Polar / CosineHemisphere / TriUniform   samplers.metal:200-238
+// The radical inverse keeps the reference's float sequence (f *= 1/b; r += f * digit) exactly; only the integer
+// i / b and i % b are strength-reduced to a 64-bit multiply-high with a per-dimension magic number
+// (HaltonEntry), which is exact for every 32-bit i.
+#pragma once
+#include "pt_device.h"
+
+namespace pt {
+
+constexpr float kOneMinusEpsilon = 0x1.fffffep-1;  // defs.metal:22
+
+PT_HD uint32_t pcg4d_x(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+  x = x * 1664525u + 1013904223u;
+  y = y * 1664525u + 1013904223u;
+  z = z * 1664525u + 1013904223u;
+  w = w * 1664525u + 1013904223u;
+  x += y * w; y += z * x; z += x * y; w += y * z;
+  x ^= x >> 16u; y ^= y >> 16u; z ^= z >> 16u; w ^= w >> 16u;
+  x += y * w;  // only .x is consumed by HaltonSampler (samplers.metal:155)
+  return x;
+}
+
+PT_HD uint32_t halton_offset(uint32_t px, uint32_t py, uint32_t sample) { return pcg4d_x(px, py, sample, px + py); }
+
+PT_HD float halton(const HaltonEntry* __restrict__ tab, uint32_t i, uint32_t d) {
+  const HaltonEntry e = tab[d];
+  float f = 1.0f;
+  float r = 0.0f;
+  while (i > 0) {
+    f = f * e.inv;
+    // q = i / prime via (M * i) >> 64, M = magic_hi:magic_lo
+    uint64_t t = (uint64_t)e.magic_hi * i + (((uint64_t)e.magic_lo * i) >> 32);
+    uint32_t q = (uint32_t)(t >> 32);
+    uint32_t digit = i - q * e.prime;
+    r = r + f * (float)digit;
+    i = q;
+  }
+  return fminf(r, kOneMinusEpsilon);
+}
+
+// A sampler cursor: (offset, dim) live in the path state between kernels.
+struct Halton {
+  const HaltonEntry* tab;
+  uint32_t offset;
+  uint32_t dim;
+  PT_HD float sample1d() { return halton(tab, offset, dim++); }
+  PT_HD vec2 sample2d() {
+    float x = halton(tab, offset, dim++);
+    float y = halton(tab, offset, dim++);
+    return {x, y};
+  }
+};
+
+PT_HD vec2 sampleDisk(vec2 u) {
+  const float r = sqrtf(u.x);
+  const float theta = 2.0f * kPi * u.y;
+  float s, c;
+  sincos_det(theta, &s, &c);
+  return {r * c, r * s};
+}
+PT_HD vec2 sampleDiskPolar(vec2 u) { return {sqrtf(u.x), 2.0f * kPi * u.y}; }
+PT_HD vec3 sampleCosineHemisphere(vec2 u) {
+  const float phi = u.x * 2.0f * kPi;
+  const float sinTheta = sqrtf(u.y);
+  const float cosTheta = sqrtf(1.0f - u.y);
+  float sinPhi, cosPhi;
+  sincos_det(phi, &sinPhi, &cosPhi);
+  return {cosPhi * sinTheta, sinPhi * sinTheta, cosTheta};
+}
+PT_HD vec2 sampleTriUniform(vec2 u) {
+  float b0, b1;
+  if (u.x < u.y) {
+    b0 = u.x * 0.5f;
+    b1 = u.y - b0;
+  } else {
+    b1 = u.y * 0.5f;
+    b0 = u.x - b1;
+  }
+  return {b0, b1};
+}
+
+}  // namespace pt

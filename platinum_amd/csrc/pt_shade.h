@@ -1,0 +1,239 @@
+// pt_shade.h — per-path stage functions of the wavefront integrator: everything `misKernel`
+// (kernel.metal:473-686) and `pathtracingKernel` (:256-372) do between two `intersect` calls.
+//
+//   stage_raygen  : HaltonSampler ctor + spawnRayFromCamera                     kernel.metal:195-238, 491-498
+//   stage_shade   : getIntersectionData, BSDF sample, emitted + MIS, NEE set-up, kernel.metal:118-188, 545-669
+//                   throughput, Russian roulette, next ray
+// The callers (kernels.hip) own queues, compaction and memory traffic; these functions are pure per-path math so
+// that tests/emu can run them on the host for debugging.
+#pragma once
+#include "pt_bsdf.h"
+#include "pt_bvh.h"
+
+namespace pt {
+
+// kernel.metal:40-69
+struct Frame {
+  vec3 x, y, z;
+  PT_HD vec3 worldToLocal(vec3 w) const { return {dot(w, x), dot(w, y), dot(w, z)}; }
+  PT_HD vec3 localToWorld(vec3 l) const { return (x * l.x + y * l.y) + z * l.z; }
+};
+PT_HD Frame frame_from_normal(vec3 n) {  // :43-50
+  const vec3 a = fabsf(n.x) > 0.5f ? v3(0.0f, 0.0f, 1.0f) : v3(1.0f, 0.0f, 0.0f);
+  const vec3 b = normalize(cross(n, a));
+  const vec3 t = cross(n, b);
+  return {t, b, n};
+}
+PT_HD Frame frame_from_nt(vec3 n, vec3 t, float sgn) {  // :52-60
+  if (fabsf(dot(n, t)) > 0.9f) return frame_from_normal(n);
+  const vec3 b = normalize(cross(n, t)) * sgn;
+  t = cross(b, n);
+  return {t, b, n};
+}
+
+struct Xform { vec3 c0, c1, c2, c3; };
+PT_HD Xform load_xform(const InstanceInfo& in) {
+  return {v3(in.c0[0], in.c0[1], in.c0[2]), v3(in.c1[0], in.c1[1], in.c1[2]), v3(in.c2[0], in.c2[1], in.c2[2]),
+          v3(in.c3[0], in.c3[1], in.c3[2])};
+}
+PT_HD vec3 transformVec(vec3 p, const Xform& m) { return (m.c0 * p.x + m.c1 * p.y) + m.c2 * p.z; }             // :10-13
+PT_HD vec3 transformPoint(vec3 p, const Xform& m) { return ((m.c0 * p.x + m.c1 * p.y) + m.c2 * p.z) + m.c3; }  // :15-18
+PT_HD vec3 ld3(const pt_float3& v) { return v3(v.x, v.y, v.z); }
+
+// defs.metal:27-30
+PT_HD vec3 interpolate3(vec3 a0, vec3 a1, vec3 a2, float u, float v) { return ((1.0f - u - v) * a0 + u * a1) + v * a2; }
+
+// ---- raygen -----------------------------------------------------------------------------------------------------
+struct RayGenOut { vec3 o, d; uint32_t offset, dim; };
+
+PT_HD RayGenOut stage_raygen(const DeviceScene& S, uint32_t px, uint32_t py, uint32_t sample) {
+  Halton h{S.halton, halton_offset(px, py, sample), 0};
+  const vec2 pixelSample = h.sample2d();  // dims 0-1 (kernel.metal:497)
+  const vec2 lensSample = h.sample2d();   // dims 2-3
+  const pt_camera_data& cam = S.camera;
+  vec3 origin = ld3(cam.position);
+  if (cam.apertureRadius > 0.0f) {  // kernel.metal:205-226
+    vec2 lensPos = sampleDiskPolar(lensSample);
+    lensPos.x = powr_det(lensPos.x, exp2_det(cam.bokehPower));
+    if (cam.apertureRoundness < 1.0f) {
+      const float n = (float)cam.apertureBlades;
+      const float rPolygon = cos_det(kPi / n) / cos_det(fmodf(lensPos.y + 1.5f * kPi, 2.0f * kPi / n) - kPi / n);
+      const float r = mix(rPolygon, 1.0f, cam.apertureRoundness);
+      lensPos.x = lensPos.x * r;
+    }
+    float s, c;
+    sincos_det(lensPos.y, &s, &c);
+    const float lx = lensPos.x * c * cam.apertureRadius;
+    const float ly = lensPos.x * s * cam.apertureRadius;
+    origin = origin + (lx * normalize(ld3(cam.pixelDeltaU)) + ly * normalize(ld3(cam.pixelDeltaV)));
+  }
+  const float fx = (float)px + pixelSample.x;
+  const float fy = (float)py + pixelSample.y;
+  RayGenOut out;
+  out.o = origin;
+  out.d = normalize(((ld3(cam.topLeft) + fx * ld3(cam.pixelDeltaU)) + fy * ld3(cam.pixelDeltaV)) - origin);
+  out.offset = h.offset;
+  out.dim = h.dim;
+  return out;
+}
+
+// ---- shade ------------------------------------------------------------------------------------------------------
+struct ShadeIn {
+  vec3 o, d;          // the ray that produced the hit
+  vec3 att;           // attenuation (throughput) before this bounce
+  float lastPdf;      // lastSample.pdf
+  bool lastSpecular;  // lastSample.flags & Sample_Specular
+  uint32_t offset, dim;
+  uint32_t bounce;
+  float t, u, v;      // hit
+  uint32_t tri;       // index into S.tris
+};
+struct ShadeOut {
+  vec3 emitted;        // to add to the path radiance now (already multiplied by attenuation and MIS weight)
+  bool has_emitted;
+  bool shadow;         // NEE shadow ray requested
+  vec3 shadow_o, shadow_d;
+  float shadow_tmax;
+  vec3 shadow_contrib; // attenuation * Ld, to add if the shadow ray is unoccluded
+  bool alive;          // path continues to bounce + 1
+  vec3 next_o, next_d, next_att;
+  float next_pdf;
+  bool next_specular;
+  uint32_t dim;
+};
+
+// kernel.metal:379-394
+PT_HD uint32_t sampleLightPower(const DeviceScene& S, float r) {
+  r = r * S.totalLightPower;
+  uint32_t sz = S.lightCount - 1, idx = 0u;
+  while (sz > 0) {
+    const uint32_t h = sz >> 1, middle = idx + h;
+    const bool res = S.lights[middle].cumulativePower < r;
+    idx = res ? (middle + 1) : idx;
+    sz = res ? sz - (h + 1) : h;
+  }
+  return idx > S.lightCount - 1 ? S.lightCount - 1 : idx;
+}
+
+PT_HD ShadeOut stage_shade(const DeviceScene& S, const ShadeIn& in) {
+  ShadeOut out;
+  out.has_emitted = false;
+  out.shadow = false;
+  out.alive = false;
+  out.emitted = v3(0.0f);
+  const bool mis = S.integrator == PT_INTEGRATOR_MIS;
+  Halton halton{S.halton, in.offset, in.dim};
+
+  // ---- Resources::getIntersectionData (kernel.metal:118-188) ----
+  const TriRec* __restrict__ trp = &S.tris[in.tri];
+  const uint32_t instanceIdx = trp->inst;
+  const uint32_t primitiveId = trp->prim;
+  const InstanceInfo inst = S.instances[instanceIdx];
+  const MeshInfo mesh = S.meshes[inst.mesh];
+  const uint32_t* __restrict__ idx = &S.indices[3 * (size_t)(mesh.tri_base + primitiveId)];
+  const uint32_t i0 = mesh.vertex_base + idx[0], i1 = mesh.vertex_base + idx[1], i2 = mesh.vertex_base + idx[2];
+  const uint32_t materialSlot = S.slots[mesh.tri_base + primitiveId];
+  const pt_material_gpu material = S.materials[inst.material_base + materialSlot];
+
+  const vec3 p0 = ld3(S.positions[i0]), p1 = ld3(S.positions[i1]), p2 = ld3(S.positions[i2]);
+  const pt_vertex_data vd0 = S.vdata[i0], vd1 = S.vdata[i1], vd2 = S.vdata[i2];
+  const float tangentSign = vd0.tangent[3];
+
+  const vec3 surfaceNormal = interpolate3(ld3(vd0.normal), ld3(vd1.normal), ld3(vd2.normal), in.u, in.v);
+  const vec3 surfaceTangent = interpolate3(v3(vd0.tangent[0], vd0.tangent[1], vd0.tangent[2]),
+                                           v3(vd1.tangent[0], vd1.tangent[1], vd1.tangent[2]),
+                                           v3(vd2.tangent[0], vd2.tangent[1], vd2.tangent[2]), in.u, in.v);
+  // surfaceUV (kernel.metal:143) only feeds texture fetches — a "next" row
+  const vec3 geometricNormal = normalize(cross(p1 - p0, p2 - p0));
+
+  const Xform objectToWorld = load_xform(inst);
+  const vec3 hitPos = in.o + in.d * in.t;
+  const vec3 wsSurfaceNormal = normalize(transformVec(surfaceNormal, objectToWorld));
+  const vec3 wsSurfaceTangent = normalize(transformVec(surfaceTangent, objectToWorld));
+  const vec3 wsGeometricNormal = normalize(transformVec(geometricNormal, objectToWorld));
+  const Frame frame = frame_from_nt(wsSurfaceNormal, wsSurfaceTangent, tangentSign);
+  const vec3 wo = frame.worldToLocal(-in.d);
+
+  // ---- BSDF sample (kernel.metal:550-556) ----
+  const vec2 r01 = halton.sample2d();
+  const float r2 = halton.sample1d();
+  const float r3 = halton.sample1d();
+  const vec2 rc = halton.sample2d();
+  const ShadingContext ctx = make_shading_context(material, S.idt);
+  const BSDF bsdf(ctx, S.flags, S.luts);
+  const BsdfSample sample = bsdf.sample(wo, vec4{r01.x, r01.y, r2, r3}, rc);
+
+  // ---- light hit (kernel.metal:560-576; :325-327 for the simple integrator) ----
+  if (sample.flags & Sample_Emitted) {
+    out.has_emitted = true;
+    if (!mis || in.bounce == 0 || in.lastSpecular) {
+      out.emitted = in.att * sample.Le;
+    } else {
+      // lastHit.pos is the origin of the current ray (kernel.metal:582, 666-669)
+      const float lightPdf = (sample.Le.y * kPi / S.totalLightPower) * length_squared(in.o - hitPos) /
+                             fabsf(dot(in.d, wsGeometricNormal));
+      const float bsdfWeight = in.lastPdf / (in.lastPdf + lightPdf);
+      out.emitted = in.att * bsdfWeight * sample.Le;
+    }
+  }
+
+  // ---- next-event estimation (kernel.metal:587-639) ----
+  if (mis && (ctx.roughness > 0.0f || ctx.metallic + ctx.transmission < 1.0f)) {
+    const vec2 rl = halton.sample2d();
+    float rz = halton.sample1d();
+    if (S.lightCount > 0) {  // no env lights in this ABI version => pInfinite = 0 (kernel.metal:593-596)
+      const float pInfinite = 0.0f;
+      rz = (rz - pInfinite) / (1.0f - pInfinite);
+      const pt_area_light light = S.lights[sampleLightPower(S, rz)];
+      const float pLight = (1.0f - pInfinite) * light.power / S.totalLightPower;
+      // sampleAreaLight (kernel.metal:407-435)
+      const InstanceInfo linst = S.instances[light.instanceIdx];
+      const uint32_t vb = S.meshes[linst.mesh].vertex_base;
+      const vec3 q0 = ld3(S.positions[vb + light.indices[0]]);
+      const vec3 q1 = ld3(S.positions[vb + light.indices[1]]);
+      const vec3 q2 = ld3(S.positions[vb + light.indices[2]]);
+      const vec2 sc = sampleTriUniform(rl);
+      const Xform lx = load_xform(linst);
+      const vec3 osNormal = cross(q1 - q0, q2 - q0);
+      const vec3 lpos = transformPoint(interpolate3(q0, q1, q2, sc.x, sc.y), lx);
+      const vec3 lnormal = normalize(transformVec(osNormal, lx));
+      const vec3 lwi = normalize(lpos - hitPos);
+      const float lpdf = length_squared(lpos - hitPos) / (fabsf(dot(lnormal, lwi)) * light.area);
+
+      const vec3 wi = frame.worldToLocal(lwi);
+      const BsdfEval ev = bsdf.eval(wo, wi);
+      if (length_squared(ev.f) > 0.0f) {
+        halton.dim++;  // `ir` payload of the shadow ray (kernel.metal:625)
+        const float pdfLight = pLight * lpdf;
+        const vec3 Ld = ld3(light.emission) * ev.f * fabsf(wi.z) / (pdfLight + ev.pdf);
+        out.shadow = true;
+        out.shadow_o = hitPos;
+        out.shadow_d = lwi;
+        out.shadow_tmax = length(lpos - hitPos) - 1e-3f;
+        out.shadow_contrib = in.att * Ld;
+      }
+    }
+  }
+
+  out.dim = halton.dim;
+  if (!(sample.flags & (Sample_Reflected | Sample_Transmitted))) return out;  // kernel.metal:644-645
+
+  vec3 att = in.att * (sample.f * fabsf(sample.wi.z) / sample.pdf);  // :650
+  if (in.bounce > 0) {                                               // :655-661
+    const float q = fmaxf(0.0f, 1.0f - fmaxf(att.x, fmaxf(att.y, att.z)));
+    if (halton.sample1d() < q) { out.dim = halton.dim; return out; }
+    att = att / (1.0f - q);
+  }
+  out.dim = halton.dim;
+  if (in.bounce + 1 >= S.max_bounces) return out;  // the `bounce < MAX_BOUNCES` loop bound (kernel.metal:509)
+
+  out.alive = true;
+  out.next_o = hitPos;
+  out.next_d = normalize(frame.localToWorld(sample.wi));  // :667
+  out.next_att = att;
+  out.next_pdf = sample.pdf;
+  out.next_specular = (sample.flags & Sample_Specular) != 0;
+  return out;
+}
+
+}  // namespace pt

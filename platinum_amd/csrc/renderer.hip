@@ -1,0 +1,596 @@
+// renderer.hip — host driver behind the C ABI (include/ptamd.h): the MI355X counterpart of
+// `pt::renderer_pt::Renderer` (src/renderer_pt/renderer_pt.{hpp,cpp}).
+//
+//   pt_create          Renderer::Renderer + loadGgxLutTextures            renderer_pt.cpp:18-60, 385-446
+//   pt_start_render    startRender + the rebuild* half of render()         :72-111, 199-217, 448-651, 838-1021
+//   pt_render_step     render() steady state                               :113-197
+//   pt_status/...      status / renderProgress / renderTime                :1023-1037
+//   pt_read_accumulator  (the reference only reads back RGBA8, :1039-1059; the float mean is the parity surface)
+//
+// No CPU path exists in this library: without a HIP device pt_create fails.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host_scene.h"
+#include "kernels.h"
+
+using namespace pt;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define PT_HIP(call)                                                                                       \
+  do {                                                                                                     \
+    hipError_t e_ = (call);                                                                                \
+    if (e_ != hipSuccess) {                                                                                \
+      char buf_[512];                                                                                      \
+      snprintf(buf_, sizeof(buf_), "%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return fail(e_ == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP, buf_);                     \
+    }                                                                                                      \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * count);
+  }
+  hipError_t upload(const std::vector<T>& v) {
+    hipError_t e = alloc(v.size());
+    if (e != hipSuccess || v.empty()) return e;
+    return hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice);
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+enum KernelClass { K_RAYGEN = 0, K_CLOSEST, K_SHADE, K_SHADOW, K_ACCUM, K_CLASSES };
+
+struct TimedLaunch { int cls; hipEvent_t start, stop; };
+
+}  // namespace
+
+struct pt_renderer {
+  int device = 0;
+  int num_cu = 256;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+
+  // create-time tables
+  DevBuf<float> lut_data;
+  LutSet luts{};
+  uint32_t lut_w_E = 0, lut_w_Eavg = 0;
+  DevBuf<HaltonEntry> halton;
+
+  // scene (valid after pt_start_render)
+  bool started = false;
+  DevBuf<pt_float3> positions;
+  DevBuf<pt_vertex_data> vdata;
+  DevBuf<uint32_t> indices, slots;
+  DevBuf<MeshInfo> meshes;
+  DevBuf<InstanceInfo> instances;
+  DevBuf<pt_material_gpu> materials;
+  DevBuf<pt_area_light> lights_d;
+  std::vector<pt_area_light> lights;
+  LbvhResult bvh{};
+  DeviceScene S{};
+  pt_render_params params{};
+  pt_constants constants{};
+  uint32_t instance_count = 0, tri_count = 0;
+
+  // wavefront buffers
+  uint32_t samples_in_flight = 0;
+  size_t capacity = 0;  // path slots
+  DevBuf<vec4> st_rayO[2], st_rayD[2], st_att[2], hit, sq_o, sq_d, sq_c, Lbuf, acc_own;
+  DevBuf<uint32_t> st_pid[2], spill;
+  DevBuf<BatchCounters> ctr;
+  DevBuf<Totals> totals;
+  vec4* acc = nullptr;
+  uint32_t grid = 0;
+
+  // progress (renderer_pt.hpp:168-171)
+  uint64_t accumulated = 0, total = 0;
+  std::chrono::steady_clock::time_point render_start;
+  uint64_t timer_ms = 0;
+
+  // measurement
+  bool profiling = false;
+  std::vector<TimedLaunch> timed;
+  double ms_class[K_CLASSES] = {0, 0, 0, 0, 0};
+  uint64_t launches[K_CLASSES] = {0, 0, 0, 0, 0};
+  double upload_ms = 0, bvh_ms = 0;
+
+  PathState path_state(int k) { return PathState{st_rayO[k].p, st_rayD[k].p, st_att[k].p, st_pid[k].p}; }
+  ShadowQueue shadow_queue() { return ShadowQueue{sq_o.p, sq_d.p, sq_c.p}; }
+
+  void free_scene() {
+    positions.release(); vdata.release(); indices.release(); slots.release(); meshes.release(); instances.release();
+    materials.release(); lights_d.release();
+    if (bvh.nodes) (void)hipFree(bvh.nodes);
+    if (bvh.tris) (void)hipFree(bvh.tris);
+    bvh = LbvhResult{};
+    for (int k = 0; k < 2; k++) { st_rayO[k].release(); st_rayD[k].release(); st_att[k].release(); st_pid[k].release(); }
+    hit.release(); sq_o.release(); sq_d.release(); sq_c.release(); Lbuf.release(); acc_own.release(); spill.release();
+    acc = nullptr;
+    started = false;
+  }
+  void drop_timed() {
+    for (auto& t : timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    timed.clear();
+  }
+};
+
+namespace {
+
+struct ScopedTimer {  // records a pair of events around one launch when profiling is on
+  pt_renderer* r;
+  int cls;
+  hipEvent_t start = nullptr, stop = nullptr;
+  ScopedTimer(pt_renderer* r_, int cls_) : r(r_), cls(cls_) {
+    if (!r->profiling) return;
+    if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) { start = stop = nullptr; return; }
+    (void)hipEventRecord(start, r->stream);
+  }
+  ~ScopedTimer() {
+    if (!start) return;
+    (void)hipEventRecord(stop, r->stream);
+    r->timed.push_back({cls, start, stop});
+  }
+};
+
+enum BatchMode { BATCH_RENDER, BATCH_DEBUG, BATCH_MEASURE };
+
+// One batch: `ns` samples of every pixel, first sample index `first`, `n0` samples already in the accumulator.
+int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, BatchMode mode, int32_t* hitlog) {
+  const DeviceScene& S = r->S;
+  hipStream_t s = r->stream;
+  BatchCounters* ctr = r->ctr.p;
+  PT_HIP(hipMemsetAsync(ctr, 0, sizeof(BatchCounters), s));
+  const bool count = mode == BATCH_MEASURE;
+  {
+    ScopedTimer t(r, K_RAYGEN);
+    launch_raygen(s, S, r->path_state(0), r->Lbuf.p, ctr, first, ns);
+  }
+  int cur = 0;
+  const bool mis = S.integrator == PT_INTEGRATOR_MIS;
+  for (uint32_t b = 0; b < S.max_bounces; b++) {
+    {
+      ScopedTimer t(r, K_CLOSEST);
+      launch_trace_closest(s, r->grid, S, r->path_state(cur), r->hit.p, ctr, b, r->spill.p, hitlog, S.width * S.height, count);
+    }
+    {
+      ScopedTimer t(r, K_SHADE);
+      launch_shade(s, r->grid, S, r->path_state(cur), r->path_state(cur ^ 1), r->hit.p, r->shadow_queue(), r->Lbuf.p, ctr, b);
+    }
+    if (mis) {
+      ScopedTimer t(r, K_SHADOW);
+      launch_trace_shadow(s, r->grid, S, r->shadow_queue(), r->Lbuf.p, ctr, b, r->spill.p, count);
+    }
+    cur ^= 1;
+  }
+  if (mode == BATCH_RENDER) {
+    ScopedTimer t(r, K_ACCUM);
+    launch_accumulate(s, r->acc, r->Lbuf.p, S.width * S.height, ns, n0);
+  }
+  if (mode != BATCH_DEBUG) launch_fold_counters(s, ctr, r->totals.p, S.max_bounces, count);
+  PT_HIP(hipGetLastError());
+  return PT_OK;
+}
+
+void collect_timings(pt_renderer* r) {
+  for (auto& t : r->timed) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+      r->ms_class[t.cls] += ms;
+      r->launches[t.cls]++;
+    }
+  }
+  r->drop_timed();
+}
+
+int load_luts(pt_renderer* r, const uint8_t* b, size_t size) {
+  if (size < 12 + 16 * 8 || memcmp(b, "PTLUT01\0", 8) != 0) return fail(PT_ERR_BAD_LUT, "LUT blob: bad magic (expected PTLUT01)");
+  uint32_t count;
+  memcpy(&count, b + 8, 4);
+  if (count != 8) return fail(PT_ERR_BAD_LUT, "LUT blob: expected 8 tables (renderer_pt.hpp:154-165)");
+  uint32_t hdr[32];
+  memcpy(hdr, b + 12, sizeof(hdr));
+  const size_t data_off = 12 + 16 * 8;
+  const size_t nfloats = (size - data_off) / 4;
+  // expected shapes (renderer_pt.hpp:154-165 + resource/lut): E 128x128, Eavg 128, 3-D 32^3, 2-D avg 32^2
+  const uint32_t expect[8][3] = {{128, 128, 1}, {128, 1, 1}, {32, 32, 32}, {32, 32, 1}, {32, 32, 32}, {32, 32, 32}, {32, 32, 1}, {32, 32, 1}};
+  for (int i = 0; i < 8; i++) {
+    const uint32_t w = hdr[4 * i], h = hdr[4 * i + 1], d = hdr[4 * i + 2], off = hdr[4 * i + 3];
+    if (w != expect[i][0] || h != expect[i][1] || d != expect[i][2] || (size_t)off + (size_t)w * h * d > nfloats)
+      return fail(PT_ERR_BAD_LUT, "LUT blob: unexpected table shape");
+  }
+  std::vector<float> data(nfloats);
+  memcpy(data.data(), b + data_off, nfloats * 4);
+  PT_HIP(r->lut_data.upload(data));
+  Lut* ls[6] = {&r->luts.E, &r->luts.Eavg, &r->luts.EMs, &r->luts.EavgMs, &r->luts.ETransIn, &r->luts.ETransOut};
+  for (int i = 0; i < 6; i++) {
+    ls[i]->w = (int)hdr[4 * i]; ls[i]->h = (int)hdr[4 * i + 1]; ls[i]->depth = (int)hdr[4 * i + 2];
+    ls[i]->d = r->lut_data.p + hdr[4 * i + 3];
+  }
+  r->lut_w_E = hdr[0];
+  r->lut_w_Eavg = hdr[4];
+  return PT_OK;
+}
+
+int build_halton_table(pt_renderer* r) {
+  std::vector<HaltonEntry> tab;
+  tab.reserve(kHaltonDims);
+  for (uint32_t c = 2; (int)tab.size() < kHaltonDims; c++) {  // defs.metal:115-194: the first 620 primes
+    bool prime = true;
+    for (uint32_t d = 2; d * d <= c; d++)
+      if (c % d == 0) { prime = false; break; }
+    if (!prime) continue;
+    const uint64_t M = ~0ull / c + 1;
+    tab.push_back({c, (uint32_t)(M >> 32), (uint32_t)M, 1.0f / (float)c});
+  }
+  PT_HIP(r->halton.upload(tab));
+  return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pt_last_error(void) { return g_last_error.c_str(); }
+
+int pt_create(const pt_create_info* info, pt_renderer** out) {
+  if (!info || !out) return fail(PT_ERR_INVALID_ARGUMENT, "pt_create: null argument");
+  *out = nullptr;
+  if (info->abi_version != PT_ABI_VERSION) return fail(PT_ERR_INVALID_ARGUMENT, "pt_create: ABI version mismatch");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(PT_ERR_NO_DEVICE, "pt_create: no HIP device available (this library has no CPU fallback)");
+  if (info->device_ordinal < 0 || info->device_ordinal >= ndev) return fail(PT_ERR_INVALID_ARGUMENT, "pt_create: bad device ordinal");
+  PT_HIP(hipSetDevice(info->device_ordinal));
+  auto* r = new pt_renderer();
+  r->device = info->device_ordinal;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, r->device) == hipSuccess) r->num_cu = prop.multiProcessorCount;
+  int rc = PT_OK;
+  do {
+    if (hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(PT_ERR_HIP, "hipStreamCreate failed"); break; }
+    r->stream = r->own_stream;
+    std::vector<uint8_t> file;
+    const uint8_t* blob = (const uint8_t*)info->lut_blob;
+    size_t size = (size_t)info->lut_blob_size;
+    if (!blob) {
+      const char* path = info->lut_path ? info->lut_path : getenv("PTAMD_LUT_PATH");
+      if (!path) { rc = fail(PT_ERR_BAD_LUT, "pt_create: no LUT blob, lut_path or $PTAMD_LUT_PATH"); break; }
+      FILE* f = fopen(path, "rb");
+      if (!f) { rc = fail(PT_ERR_BAD_LUT, std::string("pt_create: cannot open LUT file ") + path); break; }
+      fseek(f, 0, SEEK_END);
+      long n = ftell(f);
+      fseek(f, 0, SEEK_SET);
+      file.resize((size_t)n);
+      if (fread(file.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); rc = fail(PT_ERR_BAD_LUT, "pt_create: short read on LUT file"); break; }
+      fclose(f);
+      blob = file.data();
+      size = file.size();
+    }
+    if ((rc = load_luts(r, blob, size)) != PT_OK) break;
+    if ((rc = build_halton_table(r)) != PT_OK) break;
+    if (r->ctr.alloc(1) != hipSuccess || r->totals.alloc(1) != hipSuccess) { rc = fail(PT_ERR_OUT_OF_MEMORY, "counter allocation failed"); break; }
+  } while (0);
+  if (rc != PT_OK) { pt_destroy(r); return rc; }
+  *out = r;
+  return PT_OK;
+}
+
+void pt_destroy(pt_renderer* r) {
+  if (!r) return;
+  (void)hipSetDevice(r->device);
+  if (r->stream) (void)hipStreamSynchronize(r->stream);
+  r->drop_timed();
+  r->free_scene();
+  if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
+  delete r;
+}
+
+int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_render_params* p) {
+  if (!r || !scene || !p) return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: null argument");
+  if (p->width == 0 || p->height == 0 || p->spp == 0) return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: empty size or spp");
+  if (p->max_bounces < 1 || p->max_bounces > 50)
+    return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: max_bounces must be 1..50 (620 Halton dimensions, kernel.metal:5)");
+  if ((uint64_t)p->width * p->height > (1ull << 28)) return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: image too large");
+  if (p->integrator != PT_INTEGRATOR_SIMPLE && p->integrator != PT_INTEGRATOR_MIS) return fail(PT_ERR_INVALID_ARGUMENT, "bad integrator");
+  if (p->flags & PT_FLAG_GMON) return fail(PT_ERR_UNSUPPORTED, "GMoN (SURVEY §8f N1) is not part of this ABI version");
+  if (scene->instance_count && (!scene->instances || !scene->instance_materials || !scene->meshes))
+    return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: null scene arrays");
+  PT_HIP(hipSetDevice(r->device));
+  if (r->stream) PT_HIP(hipStreamSynchronize(r->stream));
+  r->drop_timed();
+  r->free_scene();
+  r->params = *p;
+  r->stream = p->stream ? (hipStream_t)p->stream : r->own_stream;
+  const auto t_up0 = std::chrono::steady_clock::now();
+
+  // ---- flatten the snapshot, derive constants and the light table (host_scene.h) ----
+  HostScene hs;
+  {
+    std::string err;
+    const int rc = build_host_scene(scene, p, r->lut_w_E, r->lut_w_Eavg, &hs, &err);
+    if (rc != PT_OK) return fail(rc, err);
+  }
+  r->instance_count = (uint32_t)hs.instances.size();
+  r->tri_count = hs.tri_count;
+  r->constants = hs.constants;
+  r->lights = hs.lights;
+  const pt_constants& C = r->constants;
+  const Mat3 idt = hs.idt;
+
+  // ---- upload ----
+  PT_HIP(r->positions.upload(hs.positions));
+  PT_HIP(r->vdata.upload(hs.vdata));
+  PT_HIP(r->indices.upload(hs.indices));
+  PT_HIP(r->slots.upload(hs.slots));
+  PT_HIP(r->meshes.upload(hs.meshes));
+  PT_HIP(r->instances.upload(hs.instances));
+  PT_HIP(r->materials.upload(hs.materials));
+  PT_HIP(r->lights_d.upload(r->lights));
+
+  DeviceScene& S = r->S;
+  memset(&S, 0, sizeof(S));
+  S.positions = r->positions.p; S.vdata = r->vdata.p; S.indices = r->indices.p; S.slots = r->slots.p;
+  S.meshes = r->meshes.p; S.instances = r->instances.p; S.materials = r->materials.p; S.lights = r->lights_d.p;
+  S.halton = r->halton.p;
+  S.luts = r->luts;
+  S.camera = C.camera;
+  S.idt = idt;
+  S.width = p->width; S.height = p->height;
+  S.lightCount = C.lightCount;
+  S.totalLightPower = C.totalLightPower;
+  S.flags = p->flags;
+  S.integrator = p->integrator;
+  S.max_bounces = p->max_bounces;
+  S.tri_count = r->tri_count;
+  S.root_ref = kInvalidRef;
+  PT_HIP(hipDeviceSynchronize());
+  r->upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count();
+
+  // ---- acceleration structure (replaces rebuildAccelerationStructures, renderer_pt.cpp:653-749) ----
+  {
+    hipEvent_t e0, e1;
+    PT_HIP(hipEventCreate(&e0));
+    PT_HIP(hipEventCreate(&e1));
+    PT_HIP(hipEventRecord(e0, r->stream));
+    hipError_t be = build_lbvh(r->stream, S, r->instance_count, r->tri_count, &r->bvh);
+    if (be != hipSuccess) {
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+      return fail(be == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP, std::string("LBVH build failed: ") + hipGetErrorString(be));
+    }
+    PT_HIP(hipEventRecord(e1, r->stream));
+    PT_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    r->bvh_ms = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    S.nodes = r->bvh.nodes;
+    S.tris = r->bvh.tris;
+    S.root_ref = r->bvh.root_ref;
+  }
+
+  // ---- wavefront buffers ----
+  const uint64_t npix = (uint64_t)p->width * p->height;
+  uint32_t sif = p->samples_in_flight;
+  if (sif == 0) {
+    const uint64_t target_paths = 8ull << 20;  // ~8 M paths in flight: >> 256 CUs x 2048 threads, 1.5 GB of state
+    sif = (uint32_t)std::max<uint64_t>(1, target_paths / npix);
+  }
+  sif = std::min<uint32_t>(std::min<uint32_t>(sif, p->spp), 256);
+  r->samples_in_flight = sif;
+  r->capacity = (size_t)npix * sif;
+  for (int k = 0; k < 2; k++) {
+    PT_HIP(r->st_rayO[k].alloc(r->capacity)); PT_HIP(r->st_rayD[k].alloc(r->capacity));
+    PT_HIP(r->st_att[k].alloc(r->capacity)); PT_HIP(r->st_pid[k].alloc(r->capacity));
+  }
+  PT_HIP(r->hit.alloc(r->capacity));
+  PT_HIP(r->sq_o.alloc(r->capacity)); PT_HIP(r->sq_d.alloc(r->capacity)); PT_HIP(r->sq_c.alloc(r->capacity));
+  PT_HIP(r->Lbuf.alloc(r->capacity));
+  r->grid = (uint32_t)r->num_cu * 8;  // persistent grid: 8 blocks (32 waves) per CU
+  PT_HIP(r->spill.alloc((size_t)r->grid * kBlock * 72));
+  if (p->external_accumulator) {
+    r->acc = (vec4*)p->external_accumulator;
+  } else {
+    PT_HIP(r->acc_own.alloc(npix));
+    r->acc = r->acc_own.p;
+  }
+  PT_HIP(hipMemsetAsync(r->acc, 0, sizeof(vec4) * npix, r->stream));
+  PT_HIP(hipMemsetAsync(r->totals.p, 0, sizeof(Totals), r->stream));
+  PT_HIP(hipStreamSynchronize(r->stream));
+
+  for (int k = 0; k < K_CLASSES; k++) { r->ms_class[k] = 0; r->launches[k] = 0; }
+  r->accumulated = 0;
+  r->total = p->spp;
+  r->started = true;
+  r->render_start = std::chrono::steady_clock::now();
+  r->timer_ms = 0;
+  return PT_OK;
+}
+
+int pt_render_step(pt_renderer* r, uint32_t max_spp) {
+  if (!r) return fail(PT_ERR_INVALID_ARGUMENT, "null renderer");
+  if (!r->started) return fail(PT_ERR_BAD_STATE, "pt_render_step before pt_start_render");
+  PT_HIP(hipSetDevice(r->device));
+  uint64_t remaining = r->total - r->accumulated;
+  uint64_t n = max_spp == 0 ? remaining : std::min<uint64_t>(max_spp, remaining);
+  while (n > 0) {
+    const uint32_t ns = (uint32_t)std::min<uint64_t>(n, r->samples_in_flight);
+    int rc = enqueue_batch(r, r->params.first_sample + (uint32_t)r->accumulated, ns, (uint32_t)r->accumulated, BATCH_RENDER, nullptr);
+    if (rc != PT_OK) return rc;
+    r->accumulated += ns;
+    n -= ns;
+  }
+  r->timer_ms = (uint64_t)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r->render_start).count();
+  return PT_OK;
+}
+
+int pt_wait(pt_renderer* r) {
+  if (!r) return fail(PT_ERR_INVALID_ARGUMENT, "null renderer");
+  PT_HIP(hipSetDevice(r->device));
+  PT_HIP(hipStreamSynchronize(r->stream));
+  collect_timings(r);
+  if (r->started)
+    r->timer_ms = (uint64_t)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r->render_start).count();
+  return PT_OK;
+}
+
+int pt_status(const pt_renderer* r) {  // renderer_pt.cpp:1023-1031
+  if (!r) return PT_STATUS_BLOCKED;
+  if (r->started && r->accumulated < r->total) return PT_STATUS_BUSY;
+  int st = PT_STATUS_READY;
+  if (r->started) st |= PT_STATUS_DONE;
+  return st;
+}
+
+int pt_progress(const pt_renderer* r, uint64_t* accumulated, uint64_t* total) {
+  if (!r || !accumulated || !total) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  *accumulated = r->accumulated;
+  *total = r->total;
+  return PT_OK;
+}
+
+uint64_t pt_render_time_ms(const pt_renderer* r) { return r ? r->timer_ms : 0; }
+
+int pt_read_accumulator(pt_renderer* r, float* rgba_out) {
+  if (!r || !rgba_out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!r->started) return fail(PT_ERR_BAD_STATE, "pt_read_accumulator before pt_start_render");
+  int rc = pt_wait(r);
+  if (rc != PT_OK) return rc;
+  PT_HIP(hipMemcpy(rgba_out, r->acc, sizeof(vec4) * (size_t)r->S.width * r->S.height, hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+void* pt_accumulator_device_ptr(pt_renderer* r) { return (r && r->started) ? (void*)r->acc : nullptr; }
+
+int pt_get_constants(const pt_renderer* r, pt_constants* out) {
+  if (!r || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
+  *out = r->constants;
+  return PT_OK;
+}
+
+int pt_get_lights(const pt_renderer* r, pt_area_light* out, uint32_t capacity, uint32_t* count) {
+  if (!r || !count) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
+  *count = (uint32_t)r->lights.size();
+  if (out)
+    for (uint32_t i = 0; i < std::min<uint32_t>(capacity, *count); i++) out[i] = r->lights[i];
+  return PT_OK;
+}
+
+int pt_trace_primary(pt_renderer* r, uint32_t sample_idx, pt_hit_record* out) {
+  if (!r || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
+  PT_HIP(hipSetDevice(r->device));
+  const uint32_t npix = r->S.width * r->S.height;
+  DevBuf<pt_hit_record> rec;
+  PT_HIP(rec.alloc(npix));
+  hipStream_t s = r->stream;
+  PT_HIP(hipMemsetAsync(r->ctr.p, 0, sizeof(BatchCounters), s));
+  launch_raygen(s, r->S, r->path_state(0), r->Lbuf.p, r->ctr.p, sample_idx, 1);
+  launch_trace_closest(s, r->grid, r->S, r->path_state(0), r->hit.p, r->ctr.p, 0, r->spill.p, nullptr, npix, false);
+  launch_hit_records(s, r->S, r->path_state(0), r->hit.p, r->ctr.p, rec.p, npix);
+  PT_HIP(hipGetLastError());
+  PT_HIP(hipStreamSynchronize(s));
+  PT_HIP(hipMemcpy(out, rec.p, sizeof(pt_hit_record) * npix, hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+int pt_debug_sample(pt_renderer* r, uint32_t sample_idx, float* radiance_out, int32_t* hits_out) {
+  if (!r) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
+  PT_HIP(hipSetDevice(r->device));
+  const size_t npix = (size_t)r->S.width * r->S.height;
+  DevBuf<int32_t> log;
+  if (hits_out) {
+    PT_HIP(log.alloc(npix * 2 * r->S.max_bounces));
+    PT_HIP(hipMemsetAsync(log.p, 0xff, sizeof(int32_t) * log.n, r->stream));
+  }
+  int rc = enqueue_batch(r, sample_idx, 1, 0, BATCH_DEBUG, log.p);
+  if (rc != PT_OK) return rc;
+  PT_HIP(hipStreamSynchronize(r->stream));
+  r->drop_timed();
+  if (radiance_out) PT_HIP(hipMemcpy(radiance_out, r->Lbuf.p, sizeof(vec4) * npix, hipMemcpyDeviceToHost));
+  if (hits_out) PT_HIP(hipMemcpy(hits_out, log.p, sizeof(int32_t) * log.n, hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+int pt_measure_traversal(pt_renderer* r, uint32_t sample_idx) {
+  if (!r) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
+  PT_HIP(hipSetDevice(r->device));
+  const bool prof = r->profiling;
+  r->profiling = false;
+  int rc = enqueue_batch(r, sample_idx, 1, 0, BATCH_MEASURE, nullptr);
+  r->profiling = prof;
+  if (rc != PT_OK) return rc;
+  PT_HIP(hipStreamSynchronize(r->stream));
+  return PT_OK;
+}
+
+int pt_set_profiling(pt_renderer* r, int enabled) {
+  if (!r) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  r->profiling = enabled != 0;
+  return PT_OK;
+}
+
+int pt_get_stats(pt_renderer* r, pt_stats* out) {
+  if (!r || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
+  int rc = pt_wait(r);
+  if (rc != PT_OK) return rc;
+  Totals t{};
+  PT_HIP(hipMemcpy(&t, r->totals.p, sizeof(Totals), hipMemcpyDeviceToHost));
+  memset(out, 0, sizeof(*out));
+  out->triangles = r->tri_count;
+  out->bvh_nodes = r->bvh.node_count;
+  out->bvh_max_depth = r->bvh.max_depth;
+  out->samples_in_flight = r->samples_in_flight;
+  out->upload_ms = r->upload_ms;
+  out->bvh_build_ms = r->bvh_ms;
+  out->closest_rays = t.closest_rays;
+  out->shadow_rays = t.shadow_rays;
+  out->shaded_hits = t.shaded_hits;
+  out->paths = t.paths;
+  out->ms_raygen = r->ms_class[K_RAYGEN]; out->ms_closest = r->ms_class[K_CLOSEST]; out->ms_shade = r->ms_class[K_SHADE];
+  out->ms_shadow = r->ms_class[K_SHADOW]; out->ms_accumulate = r->ms_class[K_ACCUM];
+  out->launches_closest = r->launches[K_CLOSEST];
+  out->launches_shadow = r->launches[K_SHADOW];
+  if (t.counted_closest) {
+    out->nodes_per_closest_ray = (double)t.nodes_closest / (double)t.counted_closest;
+    out->tris_per_closest_ray = (double)t.tris_closest / (double)t.counted_closest;
+  }
+  if (t.counted_shadow) {
+    out->nodes_per_shadow_ray = (double)t.nodes_shadow / (double)t.counted_shadow;
+    out->tris_per_shadow_ray = (double)t.tris_shadow / (double)t.counted_shadow;
+  }
+  return PT_OK;
+}
+
+}  // extern "C"

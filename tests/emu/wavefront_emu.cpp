@@ -1,0 +1,187 @@
+// TEST HARNESS ONLY (tests/emu) — runs the product's per-path stage functions (platinum_amd/csrc/pt_*.h, which are
+// plain C++ under PT_HD) on the HOST, so that stage logic can be compared with the oracle in the GPU-less
+// authoring container.  It is not part of libptamd.so, is never loaded by platinum_amd, and is not a fallback:
+// it exists to debug bit-exactness before spending GPU time.  Queues, compaction and the LBVH build (the
+// __global__ kernels) are NOT covered here — only `-m gpu` tests exercise those.
+//
+// The BVH used here is a throw-away host median-split builder that emits the product's BvhNode/TriRec layout.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../platinum_amd/csrc/host_scene.h"
+#include "../../platinum_amd/csrc/pt_shade.h"
+
+using namespace pt;
+
+namespace {
+
+struct Emu {
+  HostScene hs;
+  std::vector<float> lut;
+  std::vector<HaltonEntry> halton;
+  std::vector<TriRec> tris;
+  std::vector<BvhNode> nodes;
+  DeviceScene S{};
+  pt_render_params params{};
+};
+
+struct Box3 { float lo[3], hi[3]; };
+
+Box3 tri_box(const TriRec& t, const vec3& v1, const vec3& v2) {
+  Box3 b;
+  const float* a = t.v0; const float* p1 = &v1.x; const float* p2 = &v2.x;
+  for (int k = 0; k < 3; k++) { b.lo[k] = std::min(a[k], std::min(p1[k], p2[k])); b.hi[k] = std::max(a[k], std::max(p1[k], p2[k])); }
+  return b;
+}
+void inflate(const Box3& b, float lo[3], float hi[3]) {
+  for (int k = 0; k < 3; k++) {
+    float m = std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k]));
+    float eps = m * 8e-6f + 1e-30f;
+    lo[k] = b.lo[k] - eps; hi[k] = b.hi[k] + eps;
+  }
+}
+
+// returns ref of the subtree over order[first, first+count); boxes[] are per ORIGINAL triangle
+uint32_t build(Emu& e, std::vector<uint32_t>& order, const std::vector<Box3>& boxes, uint32_t first, uint32_t count, Box3* out_box) {
+  Box3 bb; for (int k = 0; k < 3; k++) { bb.lo[k] = 1e30f; bb.hi[k] = -1e30f; }
+  for (uint32_t i = first; i < first + count; i++)
+    for (int k = 0; k < 3; k++) { bb.lo[k] = std::min(bb.lo[k], boxes[order[i]].lo[k]); bb.hi[k] = std::max(bb.hi[k], boxes[order[i]].hi[k]); }
+  *out_box = bb;
+  if (count == 1) return kLeafBit | first;
+  int axis = 0; float ext = -1;
+  for (int k = 0; k < 3; k++) if (bb.hi[k] - bb.lo[k] > ext) { ext = bb.hi[k] - bb.lo[k]; axis = k; }
+  uint32_t mid = first + count / 2;
+  std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count, [&](uint32_t a, uint32_t b) {
+    return boxes[a].lo[axis] + boxes[a].hi[axis] < boxes[b].lo[axis] + boxes[b].hi[axis]; });
+  uint32_t idx = (uint32_t)e.nodes.size();
+  e.nodes.push_back({});
+  Box3 b0, b1;
+  uint32_t r0 = build(e, order, boxes, first, mid - first, &b0);
+  uint32_t r1 = build(e, order, boxes, mid, first + count - mid, &b1);
+  BvhNode n{};
+  inflate(b0, n.lo0, n.hi0); inflate(b1, n.lo1, n.hi1);
+  n.ref0 = r0; n.ref1 = r1;
+  e.nodes[idx] = n;
+  return idx;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const void* lut_blob, uint64_t lut_size) {
+  auto* e = new Emu();
+  e->params = *p;
+  const uint8_t* b = (const uint8_t*)lut_blob;
+  uint32_t hdr[32]; memcpy(hdr, b + 12, sizeof(hdr));
+  size_t off = 12 + 16 * 8, nf = (lut_size - off) / 4;
+  e->lut.resize(nf); memcpy(e->lut.data(), b + off, nf * 4);
+  std::string err;
+  if (build_host_scene(snap, p, hdr[0], hdr[4], &e->hs, &err) != PT_OK) { fprintf(stderr, "emu: %s\n", err.c_str()); delete e; return nullptr; }
+  for (uint32_t c = 2; (int)e->halton.size() < kHaltonDims; c++) {
+    bool prime = true;
+    for (uint32_t d = 2; d * d <= c; d++) if (c % d == 0) { prime = false; break; }
+    if (!prime) continue;
+    uint64_t M = ~0ull / c + 1;
+    e->halton.push_back({c, (uint32_t)(M >> 32), (uint32_t)M, 1.0f / (float)c});
+  }
+  // flatten to world space (same sequence as lbvh.hip k_flatten)
+  std::vector<TriRec> tmp; std::vector<Box3> boxes;
+  for (uint32_t i = 0; i < e->hs.instances.size(); i++) {
+    const InstanceInfo& in = e->hs.instances[i];
+    const MeshInfo& m = e->hs.meshes[in.mesh];
+    const Xform X = load_xform(in);
+    for (uint32_t t = 0; t < m.tri_count; t++) {
+      const uint32_t* idx = &e->hs.indices[3 * (size_t)(m.tri_base + t)];
+      vec3 v0 = transformPoint(ld3(e->hs.positions[m.vertex_base + idx[0]]), X);
+      vec3 v1 = transformPoint(ld3(e->hs.positions[m.vertex_base + idx[1]]), X);
+      vec3 v2 = transformPoint(ld3(e->hs.positions[m.vertex_base + idx[2]]), X);
+      vec3 e1 = v1 - v0, e2 = v2 - v0;
+      TriRec r; r.v0[0] = v0.x; r.v0[1] = v0.y; r.v0[2] = v0.z; r.e1[0] = e1.x; r.e1[1] = e1.y; r.e1[2] = e1.z;
+      r.e2[0] = e2.x; r.e2[1] = e2.y; r.e2[2] = e2.z; r.inst = i; r.prim = t; r.gid = in.tri_global_base + t;
+      tmp.push_back(r); boxes.push_back(tri_box(r, v1, v2));
+    }
+  }
+  std::vector<uint32_t> order(tmp.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+  uint32_t root = kInvalidRef;
+  if (!tmp.empty()) { Box3 bb; root = build(*e, order, boxes, 0, (uint32_t)tmp.size(), &bb); }
+  e->tris.resize(tmp.size());
+  for (size_t i = 0; i < order.size(); i++) e->tris[i] = tmp[order[i]];
+
+  DeviceScene& S = e->S;
+  memset(&S, 0, sizeof(S));
+  S.positions = e->hs.positions.data(); S.vdata = e->hs.vdata.data(); S.indices = e->hs.indices.data(); S.slots = e->hs.slots.data();
+  S.meshes = e->hs.meshes.data(); S.instances = e->hs.instances.data(); S.materials = e->hs.materials.data();
+  S.lights = e->hs.lights.data(); S.nodes = e->nodes.data(); S.tris = e->tris.data(); S.tri_count = (uint32_t)e->tris.size();
+  S.root_ref = root; S.halton = e->halton.data();
+  Lut* ls[6] = {&S.luts.E, &S.luts.Eavg, &S.luts.EMs, &S.luts.EavgMs, &S.luts.ETransIn, &S.luts.ETransOut};
+  for (int i = 0; i < 6; i++) { ls[i]->w = hdr[4 * i]; ls[i]->h = hdr[4 * i + 1]; ls[i]->depth = hdr[4 * i + 2]; ls[i]->d = e->lut.data() + hdr[4 * i + 3]; }
+  S.camera = e->hs.constants.camera; S.idt = e->hs.idt; S.width = p->width; S.height = p->height;
+  S.lightCount = e->hs.constants.lightCount; S.totalLightPower = e->hs.constants.totalLightPower;
+  S.flags = p->flags; S.integrator = p->integrator; S.max_bounces = p->max_bounces;
+  return e;
+}
+void emu_destroy(void* h) { delete (Emu*)h; }
+void emu_get_constants(void* h, pt_constants* out) { *out = ((Emu*)h)->hs.constants; }
+uint32_t emu_get_lights(void* h, pt_area_light* out, uint32_t cap) {
+  Emu* e = (Emu*)h;
+  for (uint32_t i = 0; i < std::min<uint32_t>(cap, (uint32_t)e->hs.lights.size()); i++) out[i] = e->hs.lights[i];
+  return (uint32_t)e->hs.lights.size();
+}
+
+// One sample of every pixel, following the kernel sequence of kernels.hip per path.
+void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32_t* hits /*B*W*H*2 or null*/) {
+  Emu* e = (Emu*)h;
+  const DeviceScene& S = e->S;
+  const uint32_t W = S.width, H = S.height, B = S.max_bounces, NP = W * H;
+  if (hits) for (size_t i = 0; i < (size_t)B * NP * 2; i++) hits[i] = -1;
+  std::vector<uint32_t> lds(kLdsStack), spill(kSpillStack);
+  for (uint32_t y = 0; y < H; y++)
+    for (uint32_t x = 0; x < W; x++) {
+      const uint32_t pid = y * W + x;
+      RayGenOut rg = stage_raygen(S, x, y, sample);
+      vec3 o = rg.o, d = rg.d, att = v3(1.0f), L = v3(0.0f);
+      float lastPdf = 0.0f; bool lastSpec = false; uint32_t dim = rg.dim;
+      for (uint32_t b = 0; b < B; b++) {
+        TraversalStack st; st.lds = lds.data(); st.lds_stride = 1; st.spill = spill.data(); st.spill_stride = 1;
+        TraversalCount tc;
+        RayHit hit = traverse<false, false>(S, o, d, 1e-3f, kInf, st, &tc);
+        if (hits && hit.tri != kInvalidRef) { hits[((size_t)b * NP + pid) * 2] = S.tris[hit.tri].inst; hits[((size_t)b * NP + pid) * 2 + 1] = S.tris[hit.tri].prim; }
+        if (hit.tri == kInvalidRef) break;
+        ShadeIn in; in.o = o; in.d = d; in.att = att; in.lastPdf = lastPdf; in.lastSpecular = lastSpec; in.offset = rg.offset;
+        in.dim = dim + 1; in.bounce = b; in.t = hit.t; in.u = hit.u; in.v = hit.v; in.tri = hit.tri;
+        ShadeOut out = stage_shade(S, in);
+        if (out.has_emitted) L = L + out.emitted;
+        if (out.shadow) {
+          RayHit sh = traverse<true, false>(S, out.shadow_o, out.shadow_d, 1e-3f, out.shadow_tmax, st, &tc);
+          if (sh.tri == kInvalidRef) L = L + out.shadow_contrib;
+        }
+        if (!out.alive) break;
+        o = out.next_o; d = out.next_d; att = out.next_att; lastPdf = out.next_pdf; lastSpec = out.next_specular;
+        dim = out.dim & kMetaDimMask;
+      }
+      radiance[4 * pid] = L.x; radiance[4 * pid + 1] = L.y; radiance[4 * pid + 2] = L.z; radiance[4 * pid + 3] = 1.0f;
+    }
+}
+
+void emu_trace_primary(void* h, uint32_t sample, pt_hit_record* out) {
+  Emu* e = (Emu*)h;
+  const DeviceScene& S = e->S;
+  std::vector<uint32_t> lds(kLdsStack), spill(kSpillStack);
+  for (uint32_t y = 0; y < S.height; y++)
+    for (uint32_t x = 0; x < S.width; x++) {
+      RayGenOut rg = stage_raygen(S, x, y, sample);
+      TraversalStack st; st.lds = lds.data(); st.lds_stride = 1; st.spill = spill.data(); st.spill_stride = 1;
+      TraversalCount tc;
+      RayHit hit = traverse<false, false>(S, rg.o, rg.d, 1e-3f, kInf, st, &tc);
+      pt_hit_record& r = out[y * S.width + x];
+      if (hit.tri != kInvalidRef) { r.t = hit.t; r.u = hit.u; r.v = hit.v; r.instance = S.tris[hit.tri].inst; r.primitive = S.tris[hit.tri].prim; }
+      else { r.t = r.u = r.v = 0; r.instance = r.primitive = -1; }
+    }
+}
+float emu_halton(void* h, uint32_t i, uint32_t d) { return halton(((Emu*)h)->halton.data(), i, d); }
+
+}  // extern "C"
