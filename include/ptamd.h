@@ -34,6 +34,10 @@ enum { PT_STATUS_BLOCKED = 0, PT_STATUS_READY = 1, PT_STATUS_BUSY = 4, PT_STATUS
 enum { PT_INTEGRATOR_SIMPLE = 0, PT_INTEGRATOR_MIS = 1 };
 /* pt_shader_defs.hpp:75-79  enum RendererFlags */
 enum { PT_FLAG_NONE = 0, PT_FLAG_MULTISCATTER_GGX = 1 << 0, PT_FLAG_GMON = 1 << 1 };
+/* A path whose radiance is NaN/inf (the reference's BSDF can produce one: e.g. a NaN pdf in the rough-glass eval,
+ * about 1 path in 5e8 on C2) poisons its pixel's running mean for good in the reference (kernel.metal:672-684).
+ * PROPAGATE keeps that behaviour (parity default); ZERO counts the sample as black and reports it in pt_stats. */
+enum { PT_NONFINITE_PROPAGATE = 0, PT_NONFINITE_ZERO = 1 };
 /* pt_shader_defs.hpp:85-90  MaterialGPU::MaterialFlags */
 enum {
   PT_MATERIAL_THIN_DIELECTRIC = 1 << 0,
@@ -211,7 +215,7 @@ typedef struct pt_render_params {
   uint32_t max_bounces;        /* NEW: kernel.metal:5 hard-codes 50; 1..50 */
   uint32_t first_sample;       /* NEW: frameIdx of this renderer's first sample (multi-GPU shards) */
   uint32_t samples_in_flight;  /* NEW: samples traced concurrently per batch; 0 = auto */
-  uint32_t _reserved;
+  uint32_t nonfinite_policy;   /* NEW: PT_NONFINITE_*: what a NaN/inf sample does to the running mean */
   void* external_accumulator;  /* optional DEVICE pointer to W*H float4; NULL = library-owned */
   void* stream;                /* optional hipStream_t to enqueue on; NULL = library-owned stream */
 } pt_render_params;
@@ -272,6 +276,7 @@ typedef struct pt_stats {
   uint64_t shadow_rays;
   uint64_t shaded_hits;
   uint64_t paths;              /* pixel*samples started */
+  uint64_t nonfinite_samples;  /* samples whose radiance was NaN/inf (zeroed under PT_NONFINITE_ZERO) */
   /* device time per kernel class since pt_start_render, HIP events on the launch stream */
   double ms_raygen, ms_closest, ms_shade, ms_shadow, ms_accumulate;
   uint64_t launches_closest, launches_shadow;

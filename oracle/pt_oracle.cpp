@@ -663,7 +663,7 @@ struct orc_scene {
   Mat3 idt{};
   std::vector<pt_area_light> lights;
   std::atomic<uint64_t> n_closest{0}, n_shadow{0}, n_shaded{0}, n_paths{0}, n_nodes_closest{0}, n_tris_closest{0},
-      n_nodes_shadow{0}, n_tris_shadow{0};
+      n_nodes_shadow{0}, n_tris_shadow{0}, n_nonfinite{0};
 };
 
 namespace {
@@ -1039,7 +1039,7 @@ LightSample sampleAreaLight(const orc_scene& sc, const Hit& hit, const pt_area_l
 
 struct PathLog { int32_t* hits; uint32_t stride; uint32_t pixel; };  // hits[(bounce*stride + pixel)*2 + {0,1}]
 
-struct ThreadStats { uint64_t closest = 0, shadow = 0, shaded = 0; TraversalCounters tc_closest, tc_shadow; };
+struct ThreadStats { uint64_t closest = 0, shadow = 0, shaded = 0, nonfinite = 0; TraversalCounters tc_closest, tc_shadow; bool verbose = false; };
 
 // kernel.metal:473-686 misKernel (integrator == MIS) and :256-372 pathtracingKernel (SIMPLE), one pixel, one sample.
 // `max_bounces` replaces the compile-time MAX_BOUNCES 50 (kernel.metal:5).
@@ -1135,6 +1135,11 @@ float3 trace_path(const orc_scene& sc, uint32_t px, uint32_t py, uint32_t frameI
 
     if (!(sample.flags & (Sample_Reflected | Sample_Transmitted))) break;  // kernel.metal:644-645
 
+    if (st.verbose)
+      fprintf(stderr, "bounce %u inst %u prim %u t %g wo (%g %g %g) flags %d wi (%g %g %g) f (%g %g %g) pdf %g att (%g %g %g) L (%g %g %g) rough %g metal %g trans %g\n",
+              bounce, isect.instance_id, isect.primitive_id, isect.distance, hit.wo.x, hit.wo.y, hit.wo.z, sample.flags, sample.wi.x,
+              sample.wi.y, sample.wi.z, sample.f.x, sample.f.y, sample.f.z, sample.pdf, attenuation.x, attenuation.y, attenuation.z,
+              L.x, L.y, L.z, ctx.roughness, ctx.metallic, ctx.transmission);
     attenuation *= sample.f * fabsf(sample.wi.z) / sample.pdf;  // :650
 
     if (bounce > 0) {  // :655-661
@@ -1248,6 +1253,10 @@ int orc_render(orc_scene* sc, uint32_t first_sample, uint32_t nsamples, float* a
         float* px = &acc[4 * ((size_t)y * W + x)];
         for (uint32_t s = 0; s < nsamples; s++) {
           float3 L = trace_path(*sc, x, y, first_sample + s, nullptr, st, count_traversal != 0);
+          if (!(fabsf(L.x) <= 3.0e38f && fabsf(L.y) <= 3.0e38f && fabsf(L.z) <= 3.0e38f)) {
+            st.nonfinite++;
+            if (sc->params.nonfinite_policy == PT_NONFINITE_ZERO) L = f3(0.0f);  // build extension, see ptamd.h
+          }
           uint32_t localFrameIdx = acc_n0 + s;  // frameIdx / gmonBuckets with gmonBuckets = 1
           if (localFrameIdx > 0) {
             float3 L_prev = f3(px[0], px[1], px[2]);
@@ -1258,7 +1267,7 @@ int orc_render(orc_scene* sc, uint32_t first_sample, uint32_t nsamples, float* a
         }
       }
     }
-    sc->n_closest += st.closest; sc->n_shadow += st.shadow; sc->n_shaded += st.shaded;
+    sc->n_closest += st.closest; sc->n_shadow += st.shadow; sc->n_shaded += st.shaded; sc->n_nonfinite += st.nonfinite;
     sc->n_nodes_closest += st.tc_closest.nodes; sc->n_tris_closest += st.tc_closest.tris;
     sc->n_nodes_shadow += st.tc_shadow.nodes; sc->n_tris_shadow += st.tc_shadow.tris;
   };
@@ -1316,6 +1325,15 @@ int orc_debug_sample(orc_scene* sc, uint32_t sample_idx, float* radiance_out, in
   return 0;
 }
 
+// Verbose single-path trace to stderr (debugging aid).
+int orc_debug_pixel(orc_scene* sc, uint32_t x, uint32_t y, uint32_t sample_idx, float* L_out) {
+  ThreadStats st;
+  st.verbose = true;
+  float3 L = trace_path(*sc, x, y, sample_idx, nullptr, st, false);
+  L_out[0] = L.x; L_out[1] = L.y; L_out[2] = L.z;
+  return 0;
+}
+
 int orc_get_stats(const orc_scene* sc, orc_stats* out) {
   out->triangles = sc->tris.size();
   out->bvh_nodes = sc->bvh.size();
@@ -1323,6 +1341,7 @@ int orc_get_stats(const orc_scene* sc, orc_stats* out) {
   out->paths = sc->n_paths;
   out->nodes_closest = sc->n_nodes_closest; out->tris_closest = sc->n_tris_closest;
   out->nodes_shadow = sc->n_nodes_shadow; out->tris_shadow = sc->n_tris_shadow;
+  out->nonfinite = sc->n_nonfinite;
   return 0;
 }
 

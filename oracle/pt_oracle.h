@@ -14,6 +14,7 @@ typedef struct orc_stats {
   uint64_t triangles, bvh_nodes;
   uint64_t closest_rays, shadow_rays, shaded_hits, paths;
   uint64_t nodes_closest, tris_closest, nodes_shadow, tris_shadow;
+  uint64_t nonfinite;
 } orc_stats;
 
 // use_bvh = 0: brute force over every triangle (the definition); 1: oracle-private median-split BVH (same answers).
@@ -26,6 +27,7 @@ int orc_render(orc_scene* sc, uint32_t first_sample, uint32_t nsamples, float* a
                int count_traversal);
 int orc_trace_primary(orc_scene* sc, uint32_t sample_idx, pt_hit_record* out);
 int orc_debug_sample(orc_scene* sc, uint32_t sample_idx, float* radiance_out, int32_t* hits_out, int threads);
+int orc_debug_pixel(orc_scene* sc, uint32_t x, uint32_t y, uint32_t sample_idx, float* L_out);
 int orc_get_stats(const orc_scene* sc, orc_stats* out);
 
 uint32_t orc_halton_offset(uint32_t x, uint32_t y, uint32_t sample);

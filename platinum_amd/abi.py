@@ -17,6 +17,7 @@ INTEGRATOR_SIMPLE, INTEGRATOR_MIS = 0, 1
 FLAG_NONE, FLAG_MULTISCATTER_GGX, FLAG_GMON = 0, 1, 2
 # pt_shader_defs.hpp:85-90
 MATERIAL_THIN_DIELECTRIC, MATERIAL_USE_ALPHA, MATERIAL_EMISSIVE, MATERIAL_ANISOTROPIC = 1, 2, 4, 8
+NONFINITE_PROPAGATE, NONFINITE_ZERO = 0, 1
 
 
 class Float3(C.Structure):
@@ -111,7 +112,7 @@ class RenderParams(C.Structure):
         ("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("gmon_buckets", C.c_uint32),
         ("flags", C.c_int32), ("integrator", C.c_uint32), ("working_space", Colorspace),
         ("max_bounces", C.c_uint32), ("first_sample", C.c_uint32), ("samples_in_flight", C.c_uint32),
-        ("_reserved", C.c_uint32), ("external_accumulator", C.c_void_p), ("stream", C.c_void_p),
+        ("nonfinite_policy", C.c_uint32), ("external_accumulator", C.c_void_p), ("stream", C.c_void_p),
     ]
 
 
@@ -124,7 +125,7 @@ class Stats(C.Structure):
         ("triangles", C.c_uint64), ("bvh_nodes", C.c_uint64), ("bvh_max_depth", C.c_uint32),
         ("samples_in_flight", C.c_uint32), ("upload_ms", C.c_double), ("bvh_build_ms", C.c_double),
         ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("shaded_hits", C.c_uint64), ("paths", C.c_uint64),
-        ("ms_raygen", C.c_double), ("ms_closest", C.c_double), ("ms_shade", C.c_double), ("ms_shadow", C.c_double),
+        ("nonfinite_samples", C.c_uint64), ("ms_raygen", C.c_double), ("ms_closest", C.c_double), ("ms_shade", C.c_double), ("ms_shadow", C.c_double),
         ("ms_accumulate", C.c_double), ("launches_closest", C.c_uint64), ("launches_shadow", C.c_uint64),
         ("nodes_per_closest_ray", C.c_double), ("tris_per_closest_ray", C.c_double),
         ("nodes_per_shadow_ray", C.c_double), ("tris_per_shadow_ray", C.c_double),

@@ -16,7 +16,8 @@ void launch_shade(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState 
                   ShadowQueue sq, vec4* Lbuf, BatchCounters* ctr, uint32_t bounce);
 void launch_trace_shadow(hipStream_t s, uint32_t grid, const DeviceScene& S, ShadowQueue sq, vec4* Lbuf, BatchCounters* ctr,
                          uint32_t bounce, uint32_t* spill, bool count);
-void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npixels, uint32_t nsamples, uint32_t n0);
+void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npixels, uint32_t nsamples, uint32_t n0,
+                       uint32_t nonfinite_policy, BatchCounters* ctr);
 void launch_fold_counters(hipStream_t s, const BatchCounters* ctr, Totals* tot, uint32_t max_bounces, bool counted);
 void launch_hit_records(hipStream_t s, const DeviceScene& S, PathState st, const vec4* hit, const BatchCounters* ctr,
                         pt_hit_record* out, uint32_t npixels);

@@ -236,13 +236,18 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow(DeviceScene S, ShadowQu
 
 // ---- accumulate (kernel.metal:672-684): running mean, one sample at a time, in sample order --------------------------
 __global__ void __launch_bounds__(kBlock) k_accumulate(vec4* __restrict__ acc, const vec4* __restrict__ Lbuf,
-                                                        uint32_t npixels, uint32_t nsamples, uint32_t n0) {
+                                                        uint32_t npixels, uint32_t nsamples, uint32_t n0,
+                                                        uint32_t nonfinite_policy, BatchCounters* __restrict__ ctr) {
   const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= npixels) return;
   vec4 a = acc[p];
   for (uint32_t s = 0; s < nsamples; s++) {
     const vec4 L4 = Lbuf[(size_t)s * npixels + p];
     vec3 L = v3(L4.x, L4.y, L4.z);
+    if (!(fabsf(L.x) <= 3.0e38f && fabsf(L.y) <= 3.0e38f && fabsf(L.z) <= 3.0e38f)) {  // NaN or inf
+      atomicAdd(&ctr->nonfinite, 1u);
+      if (nonfinite_policy == PT_NONFINITE_ZERO) L = v3(0.0f);
+    }
     const uint32_t localFrameIdx = n0 + s;
     if (localFrameIdx > 0) {
       L = L + v3(a.x, a.y, a.z) * (float)localFrameIdx;
@@ -267,6 +272,7 @@ __global__ void k_fold_counters(const BatchCounters* __restrict__ ctr, Totals* _
     tot->shadow_rays += shadow;
     tot->shaded_hits += ctr->shaded;
     tot->paths += ctr->active[0];
+    tot->nonfinite += ctr->nonfinite;
   } else {  // instrumented sample (pt_measure_traversal): only feeds the per-ray fetch averages
     tot->nodes_closest += ctr->nodes_closest; tot->tris_closest += ctr->tris_closest;
     tot->nodes_shadow += ctr->nodes_shadow; tot->tris_shadow += ctr->tris_shadow;
@@ -319,8 +325,10 @@ void launch_trace_shadow(hipStream_t s, uint32_t grid, const DeviceScene& S, Sha
   else
     hipLaunchKernelGGL(k_trace_shadow<false>, dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, ctr, bounce, spill);
 }
-void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npixels, uint32_t nsamples, uint32_t n0) {
-  hipLaunchKernelGGL(k_accumulate, dim3((npixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, acc, Lbuf, npixels, nsamples, n0);
+void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npixels, uint32_t nsamples, uint32_t n0,
+                       uint32_t nonfinite_policy, BatchCounters* ctr) {
+  hipLaunchKernelGGL(k_accumulate, dim3((npixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, acc, Lbuf, npixels, nsamples, n0,
+                     nonfinite_policy, ctr);
 }
 void launch_fold_counters(hipStream_t s, const BatchCounters* ctr, Totals* tot, uint32_t max_bounces, bool counted) {
   hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, ctr, tot, max_bounces, counted ? 1u : 0u);

@@ -118,7 +118,8 @@ struct BatchCounters {
   uint32_t shadow[64];    // shadow[b]  = shadow rays queued at bounce b
   uint32_t work[192];     // dynamic-fetch cursors: [3*b + {0 closest, 1 shade, 2 shadow}]
   uint32_t shaded;        // hits shaded
-  uint32_t _pad[3];
+  uint32_t nonfinite;     // samples with NaN/inf radiance seen by k_accumulate
+  uint32_t _pad[2];
   unsigned long long nodes_closest, tris_closest, nodes_shadow, tris_shadow;  // instrumented runs only
 };
 
@@ -126,6 +127,7 @@ struct Totals {  // running totals since pt_start_render (folded from BatchCount
   unsigned long long closest_rays, shadow_rays, shaded_hits, paths;
   unsigned long long nodes_closest, tris_closest, nodes_shadow, tris_shadow;
   unsigned long long counted_closest, counted_shadow;
+  unsigned long long nonfinite;
 };
 
 }  // namespace pt

@@ -191,7 +191,7 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
   }
   if (mode == BATCH_RENDER) {
     ScopedTimer t(r, K_ACCUM);
-    launch_accumulate(s, r->acc, r->Lbuf.p, S.width * S.height, ns, n0);
+    launch_accumulate(s, r->acc, r->Lbuf.p, S.width * S.height, ns, n0, r->params.nonfinite_policy, ctr);
   }
   if (mode != BATCH_DEBUG) launch_fold_counters(s, ctr, r->totals.p, S.max_bounces, count);
   PT_HIP(hipGetLastError());
@@ -319,6 +319,7 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
     return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: max_bounces must be 1..50 (620 Halton dimensions, kernel.metal:5)");
   if ((uint64_t)p->width * p->height > (1ull << 28)) return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: image too large");
   if (p->integrator != PT_INTEGRATOR_SIMPLE && p->integrator != PT_INTEGRATOR_MIS) return fail(PT_ERR_INVALID_ARGUMENT, "bad integrator");
+  if (p->nonfinite_policy > PT_NONFINITE_ZERO) return fail(PT_ERR_INVALID_ARGUMENT, "bad nonfinite_policy");
   if (p->flags & PT_FLAG_GMON) return fail(PT_ERR_UNSUPPORTED, "GMoN (SURVEY §8f N1) is not part of this ABI version");
   if (scene->instance_count && (!scene->instances || !scene->instance_materials || !scene->meshes))
     return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: null scene arrays");
@@ -578,6 +579,7 @@ int pt_get_stats(pt_renderer* r, pt_stats* out) {
   out->shadow_rays = t.shadow_rays;
   out->shaded_hits = t.shaded_hits;
   out->paths = t.paths;
+  out->nonfinite_samples = t.nonfinite;
   out->ms_raygen = r->ms_class[K_RAYGEN]; out->ms_closest = r->ms_class[K_CLOSEST]; out->ms_shade = r->ms_class[K_SHADE];
   out->ms_shadow = r->ms_class[K_SHADOW]; out->ms_accumulate = r->ms_class[K_ACCUM];
   out->launches_closest = r->launches[K_CLOSEST];

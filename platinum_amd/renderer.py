@@ -13,12 +13,13 @@ from . import abi, scenes
 
 def make_params(width, height, spp, max_bounces, flags=abi.FLAG_MULTISCATTER_GGX, integrator=abi.INTEGRATOR_MIS,
                 working_space=scenes.BT2020, gmon_buckets=1, first_sample=0, samples_in_flight=0,
-                external_accumulator=None, stream=None):
+                external_accumulator=None, stream=None, nonfinite_policy=abi.NONFINITE_PROPAGATE):
     p = abi.RenderParams()
     p.width, p.height, p.spp, p.gmon_buckets = width, height, spp, gmon_buckets
     p.flags, p.integrator = flags, integrator
     p.working_space = scenes.colorspace(working_space)
     p.max_bounces, p.first_sample, p.samples_in_flight = max_bounces, first_sample, samples_in_flight
+    p.nonfinite_policy = nonfinite_policy
     p.external_accumulator = external_accumulator
     p.stream = stream
     return p
@@ -63,11 +64,12 @@ class Renderer:
         self._integrator = k
 
     def startRender(self, scene, size, spp, gmonBuckets=1, workingSpace=scenes.BT2020, flags=abi.FLAG_MULTISCATTER_GGX,
-                    max_bounces=50, first_sample=0, samples_in_flight=0, external_accumulator=None, stream=None):
+                    max_bounces=50, first_sample=0, samples_in_flight=0, external_accumulator=None, stream=None,
+                    nonfinite_policy=abi.NONFINITE_PROPAGATE):
         """startRender(camera, size, spp, gmonBuckets, workingSpace, flags) (renderer_pt.hpp:38-45).
         `scene` (a scenes.Scene holding the camera node) replaces the NodeID into Store."""
         p = make_params(int(size[0]), int(size[1]), spp, max_bounces, flags, self._integrator, workingSpace, gmonBuckets,
-                        first_sample, samples_in_flight, external_accumulator, stream)
+                        first_sample, samples_in_flight, external_accumulator, stream, nonfinite_policy)
         snap = scene.snapshot()
         abi.check(self._lib, self._lib.pt_start_render(self._h, C.byref(snap.struct), C.byref(p)))
         self._params = p

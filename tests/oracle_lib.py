@@ -22,7 +22,7 @@ ORACLE_LIB = os.path.join(ORACLE_DIR, "_build", "libptoracle.so")
 class OrcStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "triangles", "bvh_nodes", "closest_rays", "shadow_rays", "shaded_hits", "paths",
-        "nodes_closest", "tris_closest", "nodes_shadow", "tris_shadow")]
+        "nodes_closest", "tris_closest", "nodes_shadow", "tris_shadow", "nonfinite")]
 
 
 _lib = None

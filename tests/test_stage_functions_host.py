@@ -1,0 +1,53 @@
+"""CPU: the product's per-path stage functions (pt_sampler.h, pt_bsdf.h, pt_bvh.h, pt_shade.h, host_scene.h) compiled
+for the host by the tests/emu harness must agree bit-for-bit with the oracle.  This is a debugging net for the
+authoring container (no GPU); the real parity tests are the `-m gpu` ones that go through libptamd.so."""
+import numpy as np
+import pytest
+
+import emu_lib
+import oracle_lib
+from platinum_amd import abi, scenes
+from platinum_amd.renderer import make_params
+
+
+@pytest.mark.parametrize("factory,integrator", [
+    (lambda: scenes.cornell_scene("bench"), abi.INTEGRATOR_MIS),
+    (lambda: scenes.cornell_scene("default"), abi.INTEGRATOR_SIMPLE),
+    (lambda: scenes.cornell_sphere_scene(), abi.INTEGRATOR_MIS),
+    (lambda: scenes.field_scene(3), abi.INTEGRATOR_MIS),
+])
+def test_stage_functions_bit_exact_vs_oracle(factory, integrator):
+    sc = factory()
+    p = make_params(72, 40, 2, 6, integrator=integrator)
+    o, e = oracle_lib.OracleScene(sc, p), emu_lib.EmuScene(sc, p)
+    assert bytes(o.constants()) == bytes(e.constants())
+    assert [bytes(a) for a in o.lights()] == [bytes(b) for b in e.lights()]
+    assert o.trace_primary(1).tobytes() == e.trace_primary(1).tobytes()
+    for s in (0, 1):
+        ro, ho = o.debug_sample(s)
+        re_, he = e.debug_sample(s)
+        assert np.array_equal(ho, he)
+        assert ro.tobytes() == re_.tobytes()
+
+
+def test_magic_division_halton_equals_oracle():
+    e = emu_lib.EmuScene(scenes.cornell_scene(), make_params(8, 8, 1, 2))
+    L = oracle_lib.lib()
+    rng = np.random.default_rng(11)
+    for i in [0, 1, 2, 0xFFFFFFFF, 0x80000000] + [int(v) for v in rng.integers(0, 2**32, 300)]:
+        for d in (0, 1, 2, 3, 4, 5, 11, 53, 54, 256, 257, 619):
+            assert e.halton(i, d) == L.orc_halton(i, d), (i, d)
+
+
+def test_thin_lens_camera_and_clearcoat_material():
+    sc = scenes.cornell_sphere_scene(transmission=0.0)
+    sc.nodes[1].materials[0].clearcoat = 0.8
+    sc.nodes[1].materials[0].metallic = 0.5
+    sc.nodes[1].materials[0].anisotropy = 0.4
+    sc.camera.aperture = 2.8; sc.camera.focus_distance = 12.0; sc.camera.roundness = 0.3; sc.camera.bokeh_power = 0.5
+    p = make_params(64, 36, 1, 5)
+    o, e = oracle_lib.OracleScene(sc, p), emu_lib.EmuScene(sc, p)
+    assert o.constants().camera.apertureRadius > 0
+    ro, ho = o.debug_sample(0)
+    re_, he = e.debug_sample(0)
+    assert np.array_equal(ho, he) and ro.tobytes() == re_.tobytes()

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Mint the self-made pins of SURVEY §8c (the reference ships no golden vectors) from the CPU oracle and commit them
+as small fixtures under tests/golden/.  Re-running must reproduce the files bit-for-bit.
+
+    python tools/make_golden.py
+
+  sampler_kat.json        integer known-answers of pcg4d / Halton offset (computed from
+                          samplers.metal:16-23,154-156 by the surveyor) + Halton values of the first dims
+  c1_cornell_golden.npz   C1 (Cornell 512x512, 4 bounces, MIS): 64x64 centre crop of the accumulator at 1 and 4 spp,
+                          per-channel means and a sha256 of the full images; primary-ray (instance, primitive) map
+                          checksum and a 64x64 crop of (t,u,v)
+  c2_small_golden.npz     Cornell + glass sphere, 160x90, 8 bounces: full accumulator at 2 spp + per-bounce hit ids of sample 0
+"""
+import hashlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_lib
+from platinum_amd import scenes
+from platinum_amd.renderer import make_params
+
+G = os.path.join(ROOT, "tests", "golden")
+os.makedirs(G, exist_ok=True)
+L = oracle_lib.lib()
+
+kat = {
+    "source": "SURVEY.md §8a (integer arithmetic of samplers.metal:16-23,154-156)",
+    "offsets": [[0, 0, 0, 0x0f02f829], [1, 0, 0, 0x87708cf9], [0, 1, 0, 0xd42dba74], [17, 5, 3, 0x5ca03064], [1919, 1079, 255, 0xe596edc1]],
+    "halton_exact": [[1, 0, 0.5], [2, 0, 0.25], [1, 1, 1.0 / 3.0]],
+    "primes": {"count": 620, "first": 2, "last": 4583},
+    "halton_bits": [[i, d, int(np.float32(L.orc_halton(i, d)).view(np.uint32))] for i in (1, 12345, 0x0f02f829, 0xffffffff) for d in (0, 1, 2, 3, 7, 100, 619)],
+}
+json.dump(kat, open(os.path.join(G, "sampler_kat.json"), "w"), indent=1)
+
+sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+# ---- C1 ----
+sc = scenes.cornell_scene("bench")
+W = H = 512
+o = oracle_lib.OracleScene(sc, make_params(W, H, 4, 4))
+acc1 = o.render(0, 1)
+acc4 = o.render(1, 3, acc=acc1.copy(), acc_n0=1)
+prim = o.trace_primary(0)
+c = slice(224, 288)
+np.savez_compressed(os.path.join(G, "c1_cornell_golden.npz"),
+                    acc1_crop=acc1[c, c], acc4_crop=acc4[c, c], acc1_mean=acc1[..., :3].mean((0, 1)), acc4_mean=acc4[..., :3].mean((0, 1)),
+                    acc1_sha=sha(acc1), acc4_sha=sha(acc4), prim_ids_sha=sha(np.stack([prim["instance"], prim["primitive"]], -1)),
+                    prim_tuv_crop=np.stack([prim["t"], prim["u"], prim["v"]], -1)[c, c], prim_ids_crop=np.stack([prim["instance"], prim["primitive"]], -1)[c, c])
+# ---- small C2 ----
+sc2 = scenes.cornell_sphere_scene()
+o2 = oracle_lib.OracleScene(sc2, make_params(160, 90, 2, 8))
+acc2 = o2.render(0, 2)
+rad0, hits0 = o2.debug_sample(0)
+np.savez_compressed(os.path.join(G, "c2_small_golden.npz"), acc2=acc2, hits0=hits0.astype(np.int16), rad0=rad0)
+for f in sorted(os.listdir(G)):
+    print(f, os.path.getsize(os.path.join(G, f)))

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output (kernel trace + separate --pmc FETCH_SIZE / WRITE_SIZE passes) for one workload into
+profiles/: copies the kernel_stats CSV, and writes per-kernel HBM traffic per launch as the guide prescribes
+(MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B
+for wide coalesced reads => reported raw AND doubled; our traversal reads are 16-B/lane gathers of 64-B nodes, an
+uncalibrated pattern, so the true read traffic lies between the two numbers)."""
+import csv, glob, json, os, shutil, sys
+from collections import defaultdict
+
+prof_dir, wl, tag = sys.argv[1], sys.argv[2], sys.argv[3]  # e.g. gpurun_out/prof c2 r01
+out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+os.makedirs(out_dir, exist_ok=True)
+
+def short(name):
+    for k in ("k_trace_closest<false>", "k_trace_closest<true>", "k_trace_shadow<false>", "k_trace_shadow<true>", "k_shade", "k_raygen",
+              "k_accumulate", "k_fold_counters", "k_refit", "k_karras", "k_emit", "k_morton", "k_flatten", "k_bounds", "k_hit_records"):
+        if k in name:
+            return k
+    if "rocprim" in name: return "rocprim_radix_sort"
+    return name[:40]
+
+stats = glob.glob(os.path.join(prof_dir, f"{wl}_trace", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(out_dir, f"{tag}_{wl}_kernel_stats.csv"))
+rows = list(csv.DictReader(open(stats)))
+summary = {}
+for r in rows:
+    k = short(r["Name"])
+    d = summary.setdefault(k, {"calls": 0, "total_ms": 0.0})
+    d["calls"] += int(r["Calls"]); d["total_ms"] += float(r["TotalDurationNs"]) / 1e6
+
+def counter(kind):
+    f = glob.glob(os.path.join(prof_dir, f"{wl}_{kind}", "*", "*_counter_collection.csv"))
+    acc = defaultdict(lambda: [0, 0.0])
+    if not f: return acc
+    for r in csv.DictReader(open(f[0])):
+        k = short(r["Kernel_Name"])
+        acc[k][0] += 1; acc[k][1] += float(r["Counter_Value"])
+    return acc
+fetch, write = counter("fetch"), counter("write")
+lines = [f"# rocprofv3 summary — bench.py --workload {wl} --steps 8 (MI355X, {tag})", "",
+         "| kernel | calls | total ms | avg ms | FETCH_SIZE KiB/launch (raw) | x2 (gfx950 corr.) | WRITE_SIZE KiB/launch |", "|---|---|---|---|---|---|---|"]
+traffic = {}
+for k, d in sorted(summary.items(), key=lambda kv: -kv[1]["total_ms"]):
+    fl = fetch[k][1] / fetch[k][0] if fetch[k][0] else float("nan")
+    wr = write[k][1] / write[k][0] if write[k][0] else float("nan")
+    lines.append(f"| {k} | {d['calls']} | {d['total_ms']:.3f} | {d['total_ms']/d['calls']:.4f} | {fl:.1f} | {2*fl:.1f} | {wr:.1f} |")
+    traffic[k] = {"fetch_kib_raw": fl, "write_kib": wr, "avg_ms": d["total_ms"] / d["calls"]}
+open(os.path.join(out_dir, f"{tag}_{wl}_summary.md"), "w").write("\n".join(lines) + "\n")
+c = traffic.get("k_trace_closest<false>")
+if c:
+    json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --workload {wl} --steps 8, {tag}",
+               "closest_hbm_bytes_per_launch": (2 * c["fetch_kib_raw"] + c["write_kib"]) * 1024,
+               "closest_fetch_bytes_raw": c["fetch_kib_raw"] * 1024, "closest_write_bytes": c["write_kib"] * 1024,
+               "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (upper bound for this gather pattern)"},
+              open(os.path.join(out_dir, f"traffic_{wl}.json"), "w"), indent=1)
+print("\n".join(lines))
