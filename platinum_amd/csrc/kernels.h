@@ -11,11 +11,11 @@ constexpr int kBlock = 256;  // 4 waves; traversal kernels keep a 24 KiB LDS sta
 void launch_raygen(hipStream_t s, const DeviceScene& S, PathState st, vec4* Lbuf, BatchCounters* ctr, uint32_t first_sample,
                    uint32_t nsamples);
 void launch_trace_closest(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, vec4* hit, BatchCounters* ctr,
-                          uint32_t bounce, uint32_t* spill, int32_t* hitlog, uint32_t log_stride, bool count);
+                          uint32_t bounce, uint32_t* spill, int32_t* hitlog, uint32_t log_stride, bool count, uint32_t refill);
 void launch_shade(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState sin, PathState sout, const vec4* hit,
                   ShadowQueue sq, vec4* Lbuf, BatchCounters* ctr, uint32_t bounce);
 void launch_trace_shadow(hipStream_t s, uint32_t grid, const DeviceScene& S, ShadowQueue sq, vec4* Lbuf, BatchCounters* ctr,
-                         uint32_t bounce, uint32_t* spill, bool count);
+                         uint32_t bounce, uint32_t* spill, bool count, uint32_t refill);
 void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npixels, uint32_t nsamples, uint32_t n0,
                        uint32_t nonfinite_policy, BatchCounters* ctr);
 void launch_fold_counters(hipStream_t s, const BatchCounters* ctr, Totals* tot, uint32_t max_bounces, bool counted);

@@ -63,49 +63,82 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DeviceScene S, PathState st, 
   }
 }
 
-// ---- closest hit ---------------------------------------------------------------------------------------------------
+// ---- traversal kernels: persistent waves with per-lane ray replacement ---------------------------------------------
+// A wave keeps up to 64 rays in flight.  Whenever fewer than `refill_threshold` lanes still hold a ray (and the queue is
+// not exhausted) the wave leaves the traversal loop, idle lanes pull new rays (ballot + one atomic per wave) and
+// everybody resumes where they were: a lane's traversal state (TravState + its LDS stack column) survives the refill.
+// This removes the "whole wave waits for its slowest ray" tail of a plain persistent loop.
+
+struct WaveQueue {
+  uint32_t* cursor;
+  uint32_t count;
+  bool exhausted;
+};
+// Idle lanes (need == true) get the index of a fresh queue entry, or kInvalidRef when the queue ran dry.
+__device__ __forceinline__ uint32_t wave_refill(WaveQueue& q, bool need, uint32_t lane) {
+  uint32_t idx = kInvalidRef;
+  if (q.exhausted) return idx;
+  const unsigned long long m = __ballot(need);
+  const uint32_t n = (uint32_t)__popcll(m);
+  if (n == 0) return idx;
+  const uint32_t base = wave_alloc(q.cursor, n, lane);
+  if (need) {
+    const uint32_t i = base + wave_prefix(m);
+    if (i < q.count) idx = i;
+  }
+  if (base + n >= q.count) q.exhausted = true;
+  return idx;
+}
+
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock) k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit,
                                                            BatchCounters* __restrict__ ctr, uint32_t bounce,
                                                            uint32_t* __restrict__ spill, int32_t* __restrict__ hitlog,
-                                                           uint32_t log_stride) {
+                                                           uint32_t log_stride, uint32_t refill_threshold) {
   __shared__ uint32_t lds_stack[kLdsStack][kBlock];
   const uint32_t lane = wave_lane();
-  const uint32_t count = ctr->active[bounce];
-  uint32_t* cursor = &ctr->work[3 * bounce + 0];
+  WaveQueue q{&ctr->work[3 * bounce + 0], ctr->active[bounce], false};
   TraversalStack stack;
   stack.lds = &lds_stack[0][threadIdx.x];
   stack.lds_stride = kBlock;
   stack.spill = spill + ((size_t)blockIdx.x * kBlock + threadIdx.x);
   stack.spill_stride = gridDim.x * kBlock;
-  uint32_t cnt_nodes = 0, cnt_tris = 0;
+  TraversalCount tc;
+  TravState ts;
+  uint32_t ray = kInvalidRef;  // queue index of the ray this lane is tracing
+
+  auto finish = [&]() {
+    const RayHit& h = ts.best;
+    hit[ray] = vec4{h.t, h.u, h.v, u2f(h.tri)};
+    if (hitlog) {
+      const uint32_t pid = st.pid[ray];
+      int32_t* hl = &hitlog[((size_t)bounce * log_stride + pid) * 2];
+      hl[0] = h.tri != kInvalidRef ? (int32_t)S.tris[h.tri].inst : -1;
+      hl[1] = h.tri != kInvalidRef ? (int32_t)S.tris[h.tri].prim : -1;
+    }
+    ray = kInvalidRef;
+  };
 
   for (;;) {
-    const uint32_t base = wave_alloc(cursor, 64, lane);
-    if (base >= count) break;
-    const uint32_t i = base + lane;
-    if (i < count) {
-      const vec4 o4 = st.rayO[i];
-      const vec4 d4 = st.rayD[i];
-      TraversalCount tc;
-      const RayHit h = traverse<false, COUNT>(S, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 1e-3f, kInf, stack, &tc);
-      hit[i] = vec4{h.t, h.u, h.v, u2f(h.tri)};
-      if (COUNT) { cnt_nodes += tc.nodes; cnt_tris += tc.tris; }
-      if (hitlog) {
-        const uint32_t pid = st.pid[i];
-        int32_t* hl = &hitlog[((size_t)bounce * log_stride + pid) * 2];
-        if (h.tri != kInvalidRef) {
-          hl[0] = (int32_t)S.tris[h.tri].inst;
-          hl[1] = (int32_t)S.tris[h.tri].prim;
-        } else {
-          hl[0] = -1;
-          hl[1] = -1;
-        }
-      }
+    const uint32_t fresh = wave_refill(q, ray == kInvalidRef, lane);
+    if (fresh != kInvalidRef) {
+      ray = fresh;
+      const vec4 o4 = st.rayO[ray];
+      const vec4 d4 = st.rayD[ray];
+      if (trav_init(S, ts, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 1e-3f, kInf, stack, false, COUNT ? &tc : nullptr)) finish();
+    }
+    if (__ballot(ray != kInvalidRef) == 0) {
+      if (q.exhausted) break;
+      continue;
+    }
+    while (ray != kInvalidRef) {
+      if (trav_step<false, COUNT>(S, ts, &tc)) finish();
+      // lanes still in this loop vote; leave for a refill when the wave got too empty
+      if (refill_threshold && !q.exhausted && (uint32_t)__popcll(__ballot(ray != kInvalidRef)) < refill_threshold) break;
     }
   }
   if (COUNT) {
-    const uint32_t n = wave_sum(cnt_nodes), t = wave_sum(cnt_tris);
+    const uint32_t n = wave_sum(tc.nodes), t = wave_sum(tc.tris);
     if (lane == 0) {
       atomicAdd(&ctr->nodes_closest, (unsigned long long)n);
       atomicAdd(&ctr->tris_closest, (unsigned long long)t);
@@ -194,39 +227,50 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene S, PathState sin, 
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock) k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf,
                                                           BatchCounters* __restrict__ ctr, uint32_t bounce,
-                                                          uint32_t* __restrict__ spill) {
+                                                          uint32_t* __restrict__ spill, uint32_t refill_threshold) {
   __shared__ uint32_t lds_stack[kLdsStack][kBlock];
   const uint32_t lane = wave_lane();
-  const uint32_t count = ctr->shadow[bounce];
-  uint32_t* cursor = &ctr->work[3 * bounce + 2];
+  WaveQueue q{&ctr->work[3 * bounce + 2], ctr->shadow[bounce], false};
   TraversalStack stack;
   stack.lds = &lds_stack[0][threadIdx.x];
   stack.lds_stride = kBlock;
   stack.spill = spill + ((size_t)blockIdx.x * kBlock + threadIdx.x);
   stack.spill_stride = gridDim.x * kBlock;
-  uint32_t cnt_nodes = 0, cnt_tris = 0;
+  TraversalCount tc;
+  TravState ts;
+  uint32_t ray = kInvalidRef;
+  uint32_t pid = 0;
+
+  auto finish = [&]() {
+    if (ts.best.tri == kInvalidRef) {  // unoccluded: L += attenuation * Ld (kernel.metal:631-637)
+      const vec4 c = sq.contrib[ray];
+      vec4 L = Lbuf[pid];
+      L.x += c.x; L.y += c.y; L.z += c.z;
+      Lbuf[pid] = L;
+    }
+    ray = kInvalidRef;
+  };
 
   for (;;) {
-    const uint32_t base = wave_alloc(cursor, 64, lane);
-    if (base >= count) break;
-    const uint32_t i = base + lane;
-    if (i < count) {
-      const vec4 o4 = sq.o[i];
-      const vec4 d4 = sq.d[i];
-      TraversalCount tc;
-      const RayHit h = traverse<true, COUNT>(S, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 1e-3f, o4.w, stack, &tc);
-      if (COUNT) { cnt_nodes += tc.nodes; cnt_tris += tc.tris; }
-      if (h.tri == kInvalidRef) {  // unoccluded: L += attenuation * Ld (kernel.metal:631-637)
-        const uint32_t pid = f2u(d4.w);
-        const vec4 c = sq.contrib[i];
-        vec4 L = Lbuf[pid];
-        L.x += c.x; L.y += c.y; L.z += c.z;
-        Lbuf[pid] = L;
-      }
+    const uint32_t fresh = wave_refill(q, ray == kInvalidRef, lane);
+    if (fresh != kInvalidRef) {
+      ray = fresh;
+      const vec4 o4 = sq.o[ray];
+      const vec4 d4 = sq.d[ray];
+      pid = f2u(d4.w);
+      if (trav_init(S, ts, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 1e-3f, o4.w, stack, true, COUNT ? &tc : nullptr)) finish();
+    }
+    if (__ballot(ray != kInvalidRef) == 0) {
+      if (q.exhausted) break;
+      continue;
+    }
+    while (ray != kInvalidRef) {
+      if (trav_step<true, COUNT>(S, ts, &tc)) finish();
+      if (refill_threshold && !q.exhausted && (uint32_t)__popcll(__ballot(ray != kInvalidRef)) < refill_threshold) break;
     }
   }
   if (COUNT) {
-    const uint32_t n = wave_sum(cnt_nodes), t = wave_sum(cnt_tris);
+    const uint32_t n = wave_sum(tc.nodes), t = wave_sum(tc.tris);
     if (lane == 0) {
       atomicAdd(&ctr->nodes_shadow, (unsigned long long)n);
       atomicAdd(&ctr->tris_shadow, (unsigned long long)t);
@@ -308,22 +352,22 @@ void launch_raygen(hipStream_t s, const DeviceScene& S, PathState st, vec4* Lbuf
   hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, s, S, st, Lbuf, ctr, first_sample, nsamples, tilesX, tilesY);
 }
 void launch_trace_closest(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, vec4* hit, BatchCounters* ctr,
-                          uint32_t bounce, uint32_t* spill, int32_t* hitlog, uint32_t log_stride, bool count) {
+                          uint32_t bounce, uint32_t* spill, int32_t* hitlog, uint32_t log_stride, bool count, uint32_t refill) {
   if (count)
-    hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(kBlock), 0, s, S, st, hit, ctr, bounce, spill, hitlog, log_stride);
+    hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(kBlock), 0, s, S, st, hit, ctr, bounce, spill, hitlog, log_stride, refill);
   else
-    hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(kBlock), 0, s, S, st, hit, ctr, bounce, spill, hitlog, log_stride);
+    hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(kBlock), 0, s, S, st, hit, ctr, bounce, spill, hitlog, log_stride, refill);
 }
 void launch_shade(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState sin, PathState sout, const vec4* hit,
                   ShadowQueue sq, vec4* Lbuf, BatchCounters* ctr, uint32_t bounce) {
   hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, s, S, sin, sout, hit, sq, Lbuf, ctr, bounce);
 }
 void launch_trace_shadow(hipStream_t s, uint32_t grid, const DeviceScene& S, ShadowQueue sq, vec4* Lbuf, BatchCounters* ctr,
-                         uint32_t bounce, uint32_t* spill, bool count) {
+                         uint32_t bounce, uint32_t* spill, bool count, uint32_t refill) {
   if (count)
-    hipLaunchKernelGGL(k_trace_shadow<true>, dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, ctr, bounce, spill);
+    hipLaunchKernelGGL(k_trace_shadow<true>, dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, ctr, bounce, spill, refill);
   else
-    hipLaunchKernelGGL(k_trace_shadow<false>, dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, ctr, bounce, spill);
+    hipLaunchKernelGGL(k_trace_shadow<false>, dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, ctr, bounce, spill, refill);
 }
 void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npixels, uint32_t nsamples, uint32_t n0,
                        uint32_t nonfinite_policy, BatchCounters* ctr) {

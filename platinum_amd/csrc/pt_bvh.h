@@ -83,75 +83,94 @@ struct TraversalStack {
 
 struct TraversalCount { uint32_t nodes = 0, tris = 0; };
 
+// Resumable traversal: one ray's state lives in registers (+ its LDS/HBM stack) and advances one node per
+// trav_step(), so a persistent kernel can hand a finished lane a new ray while its neighbours keep going.
+struct TravState {
+  vec3 o, d, inv;
+  float tmin;
+  RayHit best;     // best.t doubles as the current far limit
+  uint32_t cur;    // node to visit next
+  TraversalStack st;
+};
+
+PT_HD void trav_leaf(const DeviceScene& S, TravState& ts, uint32_t ref, bool any, bool* finished, TraversalCount* cnt) {
+  const uint32_t ti = ref & ~kLeafBit;
+  const TriRec tr = S.tris[ti];
+  if (cnt) cnt->tris++;
+  float t, u, v;
+  if (!intersect_triangle(ts.o, ts.d, ts.tmin, ts.best.t, tr, &t, &u, &v)) return;
+  if (any) {
+    ts.best.tri = ti;
+    *finished = true;
+    return;
+  }
+  // intersect_triangle admitted t <= best.t; equal t needs the id tie-break
+  if (t < ts.best.t || ts.best.tri == kInvalidRef || tr.gid < ts.best.gid) {
+    ts.best.t = t; ts.best.u = u; ts.best.v = v; ts.best.tri = ti; ts.best.gid = tr.gid;
+  }
+}
+
+// Returns true when the ray is finished (ts.best holds the answer). `st` must be the lane's stack.
+PT_HD bool trav_init(const DeviceScene& S, TravState& ts, vec3 o, vec3 d, float tmin, float tmax, TraversalStack st, bool any,
+                     TraversalCount* cnt) {
+  ts.o = o; ts.d = d; ts.tmin = tmin;
+  ts.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  ts.best.t = tmax; ts.best.u = ts.best.v = 0.0f; ts.best.tri = kInvalidRef; ts.best.gid = kInvalidRef;
+  ts.st = st;
+  ts.st.sp = 0;
+  ts.cur = S.root_ref;
+  if (S.root_ref == kInvalidRef) return true;
+  if (S.root_ref & kLeafBit) {  // single-triangle scene
+    bool fin = false;
+    trav_leaf(S, ts, S.root_ref, any, &fin, cnt);
+    return true;
+  }
+  return false;
+}
+
+template <bool ANY, bool COUNT>
+PT_HD bool trav_step(const DeviceScene& S, TravState& ts, TraversalCount* cnt) {
+  const BvhNode n = S.nodes[ts.cur];
+  if (COUNT) cnt->nodes++;
+  float d0 = slab_entry(n.lo0, n.hi0, ts.o, ts.inv, ts.tmin, ts.best.t);
+  float d1 = slab_entry(n.lo1, n.hi1, ts.o, ts.inv, ts.tmin, ts.best.t);
+  const uint32_t r0 = n.ref0, r1 = n.ref1;
+  bool finished = false;
+  // leaves are tested on the spot; they never go on the stack
+  if (d0 >= 0.0f && (r0 & kLeafBit)) {
+    trav_leaf(S, ts, r0, ANY, &finished, COUNT ? cnt : nullptr);
+    if (finished) return true;
+    d0 = -1.0f;
+  }
+  if (d1 >= 0.0f && (r1 & kLeafBit)) {
+    trav_leaf(S, ts, r1, ANY, &finished, COUNT ? cnt : nullptr);
+    if (finished) return true;
+    d1 = -1.0f;
+  }
+  if (d0 >= 0.0f && d1 >= 0.0f) {
+    // both internal children hit: descend into the nearer, defer the farther
+    const bool first0 = d0 <= d1;
+    ts.st.push(first0 ? r1 : r0);
+    ts.cur = first0 ? r0 : r1;
+  } else if (d0 >= 0.0f) {
+    ts.cur = r0;
+  } else if (d1 >= 0.0f) {
+    ts.cur = r1;
+  } else {
+    if (ts.st.sp == 0) return true;
+    ts.cur = ts.st.pop();
+    if (ts.cur == kInvalidRef) return true;
+  }
+  return false;
+}
+
 template <bool ANY, bool COUNT>
 PT_HD RayHit traverse(const DeviceScene& S, vec3 o, vec3 d, float tmin, float tmax, TraversalStack st,
                       TraversalCount* cnt) {
-  RayHit best;
-  best.t = tmax;
-  best.u = best.v = 0.0f;
-  best.tri = kInvalidRef;
-  best.gid = kInvalidRef;
-  if (S.root_ref == kInvalidRef) return best;
-
-  const vec3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  const BvhNode* __restrict__ nodes = S.nodes;
-  const TriRec* __restrict__ tris = S.tris;
-
-  auto test_leaf = [&](uint32_t ref) -> bool {
-    const uint32_t ti = ref & ~kLeafBit;
-    const TriRec tr = tris[ti];
-    if (COUNT) cnt->tris++;
-    float t, u, v;
-    if (!intersect_triangle(o, d, tmin, ANY ? tmax : best.t, tr, &t, &u, &v)) return false;
-    if (ANY) {
-      best.tri = ti;
-      return true;
-    }
-    // intersect_triangle admitted t <= best.t; equal t needs the id tie-break
-    if (t < best.t || best.tri == kInvalidRef || tr.gid < best.gid) {
-      best.t = t; best.u = u; best.v = v; best.tri = ti; best.gid = tr.gid;
-    }
-    return false;
-  };
-
-  uint32_t cur = S.root_ref;
-  if (cur & kLeafBit) {  // single-triangle scene
-    test_leaf(cur);
-    return best;
-  }
-  st.sp = 0;
-  for (;;) {
-    const BvhNode n = nodes[cur];
-    if (COUNT) cnt->nodes++;
-    const float tlimit = ANY ? tmax : best.t;
-    float d0 = slab_entry(n.lo0, n.hi0, o, inv, tmin, tlimit);
-    float d1 = slab_entry(n.lo1, n.hi1, o, inv, tmin, tlimit);
-    uint32_t r0 = n.ref0, r1 = n.ref1;
-    // leaves are tested on the spot; they never go on the stack
-    if (d0 >= 0.0f && (r0 & kLeafBit)) {
-      if (test_leaf(r0)) return best;
-      d0 = -1.0f;
-    }
-    if (d1 >= 0.0f && (r1 & kLeafBit)) {
-      if (test_leaf(r1)) return best;
-      d1 = -1.0f;
-    }
-    if (d0 >= 0.0f && d1 >= 0.0f) {
-      // both internal children hit: descend into the nearer, defer the farther
-      const bool first0 = d0 <= d1;
-      st.push(first0 ? r1 : r0);
-      cur = first0 ? r0 : r1;
-    } else if (d0 >= 0.0f) {
-      cur = r0;
-    } else if (d1 >= 0.0f) {
-      cur = r1;
-    } else {
-      if (st.sp == 0) break;
-      cur = st.pop();
-      if (cur == kInvalidRef) break;
-    }
-  }
-  return best;
+  TravState ts;
+  if (trav_init(S, ts, o, d, tmin, tmax, st, ANY, COUNT ? cnt : nullptr)) return ts.best;
+  while (!trav_step<ANY, COUNT>(S, ts, cnt)) {}
+  return ts.best;
 }
 
 }  // namespace pt

@@ -108,6 +108,7 @@ struct pt_renderer {
   DevBuf<Totals> totals;
   vec4* acc = nullptr;
   uint32_t grid = 0;
+  uint32_t refill_threshold = 0;  // traversal: refill a wave when fewer lanes than this hold a ray (0 = never)
 
   // progress (renderer_pt.hpp:168-171)
   uint64_t accumulated = 0, total = 0;
@@ -177,7 +178,7 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
   for (uint32_t b = 0; b < S.max_bounces; b++) {
     {
       ScopedTimer t(r, K_CLOSEST);
-      launch_trace_closest(s, r->grid, S, r->path_state(cur), r->hit.p, ctr, b, r->spill.p, hitlog, S.width * S.height, count);
+      launch_trace_closest(s, r->grid, S, r->path_state(cur), r->hit.p, ctr, b, r->spill.p, hitlog, S.width * S.height, count, r->refill_threshold);
     }
     {
       ScopedTimer t(r, K_SHADE);
@@ -185,7 +186,7 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
     }
     if (mis) {
       ScopedTimer t(r, K_SHADOW);
-      launch_trace_shadow(s, r->grid, S, r->shadow_queue(), r->Lbuf.p, ctr, b, r->spill.p, count);
+      launch_trace_shadow(s, r->grid, S, r->shadow_queue(), r->Lbuf.p, ctr, b, r->spill.p, count, r->refill_threshold);
     }
     cur ^= 1;
   }
@@ -270,6 +271,7 @@ int pt_create(const pt_create_info* info, pt_renderer** out) {
   PT_HIP(hipSetDevice(info->device_ordinal));
   auto* r = new pt_renderer();
   r->device = info->device_ordinal;
+  if (const char* e = getenv("PTAMD_REFILL_THRESHOLD")) r->refill_threshold = (uint32_t)atoi(e);  // tuning knob
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, r->device) == hipSuccess) r->num_cu = prop.multiProcessorCount;
   int rc = PT_OK;
@@ -515,7 +517,7 @@ int pt_trace_primary(pt_renderer* r, uint32_t sample_idx, pt_hit_record* out) {
   hipStream_t s = r->stream;
   PT_HIP(hipMemsetAsync(r->ctr.p, 0, sizeof(BatchCounters), s));
   launch_raygen(s, r->S, r->path_state(0), r->Lbuf.p, r->ctr.p, sample_idx, 1);
-  launch_trace_closest(s, r->grid, r->S, r->path_state(0), r->hit.p, r->ctr.p, 0, r->spill.p, nullptr, npix, false);
+  launch_trace_closest(s, r->grid, r->S, r->path_state(0), r->hit.p, r->ctr.p, 0, r->spill.p, nullptr, npix, false, r->refill_threshold);
   launch_hit_records(s, r->S, r->path_state(0), r->hit.p, r->ctr.p, rec.p, npix);
   PT_HIP(hipGetLastError());
   PT_HIP(hipStreamSynchronize(s));
