@@ -24,11 +24,11 @@ void launch_hit_records(hipStream_t s, const DeviceScene& S, PathState st, const
 
 // ---- LBVH (lbvh.hip) ----
 struct LbvhResult {
-  BvhNode* nodes = nullptr;   // tri_count - 1 internal nodes (hipMalloc'd; caller frees)
+  BvhNode* nodes = nullptr;   // indexed like the binary radix tree (tri_count - 1 slots, even-depth ones used)
   TriRec* tris = nullptr;     // tri_count records in leaf (Morton) order
   uint32_t root_ref = kInvalidRef;
-  uint32_t node_count = 0;
-  uint32_t max_depth = 0;
+  uint32_t node_count = 0;    // 4-wide nodes emitted
+  uint32_t max_depth = 0;     // of the binary tree
 };
 // Flattens the instanced scene to world-space triangles and builds the BVH entirely on the device.
 // `S` needs positions / indices / meshes / instances filled in. Returns hipSuccess or the failing HIP error.

@@ -7,7 +7,7 @@
 //   radix sort  rocPRIM (hipcub::DeviceRadixSort::SortPairs, 64-bit keys)
 //   k_karras    Karras 2012 radix tree: one thread per internal node, duplicate codes split by position
 //   k_refit     bottom-up AABB union, second arrival at a node proceeds (agent-scope fences around the counter)
-//   k_emit      64-byte traversal nodes with both (inflated) child boxes inline + triangles in leaf order
+//   k_emit      collapse to 4-wide 64-byte nodes (8-bit quantised, inflated child boxes) + triangles in leaf order
 //
 // Not on the per-sample hot path: runs once per pt_start_render; timed separately (pt_stats.bvh_build_ms).
 #include <hip/hip_runtime.h>
@@ -202,34 +202,44 @@ __global__ void __launch_bounds__(256) k_refit(int n, const uint2* __restrict__ 
   }
 }
 
-// Conservative inflation: the traversal's slab test must never cull a triangle the Moeller-Trumbore test accepts
-// (intersection contract). 8e-6 relative is ~64 ulp of the coordinate magnitude.
-__device__ __forceinline__ void inflate_into(const Box& b, float lo[3], float hi[3]) {
-  for (int k = 0; k < 3; k++) {
-    const float m = fmaxf(fabsf(b.lo[k]), fabsf(b.hi[k]));
-    const float eps = m * 8e-6f + 1e-30f;
-    lo[k] = b.lo[k] - eps;
-    hi[k] = b.hi[k] + eps;
-  }
-}
-
-__global__ void __launch_bounds__(256) k_emit(int n, const uint2* __restrict__ children, const Box* __restrict__ leaf_boxes,
-                                               const uint32_t* __restrict__ order, const Box* __restrict__ node_boxes,
-                                               const TriRec* __restrict__ tris_in, BvhNode* __restrict__ nodes,
-                                               TriRec* __restrict__ tris_out) {
+// Collapse the binary radix tree to 4-wide nodes: every binary node at EVEN depth becomes a BvhNode whose children are
+// its grandchildren (or a child itself where that child is a leaf).  Odd-depth nodes are absorbed.  Nodes keep their
+// binary index, so refs need no remapping.
+__global__ void __launch_bounds__(256) k_emit(int n, const uint2* __restrict__ children, const uint32_t* __restrict__ parent_int,
+                                               const Box* __restrict__ leaf_boxes, const uint32_t* __restrict__ order,
+                                               const Box* __restrict__ node_boxes, const TriRec* __restrict__ tris_in,
+                                               BvhNode* __restrict__ nodes, TriRec* __restrict__ tris_out,
+                                               uint32_t* __restrict__ emitted) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) tris_out[i] = tris_in[order[i]];
   if (i >= n - 1) return;
+  uint32_t depth = 0;
+  for (uint32_t p = (uint32_t)i; p != 0; p = parent_int[p]) depth++;
+  if (depth & 1u) return;
+  uint32_t refs[4];
+  Box3 boxes[4];
+  int count = 0;
+  auto add = [&](uint32_t ref) {
+    const Box b = (ref & kLeafBit) ? leaf_boxes[order[ref & ~kLeafBit]] : node_boxes[ref];
+    Box3 e;
+    for (int a = 0; a < 3; a++) { e.lo[a] = b.lo[a]; e.hi[a] = b.hi[a]; }
+    boxes[count] = inflate_box(e);
+    refs[count] = ref;
+    count++;
+  };
   const uint2 ch = children[i];
-  const Box a = (ch.x & kLeafBit) ? leaf_boxes[order[ch.x & ~kLeafBit]] : node_boxes[ch.x];
-  const Box b = (ch.y & kLeafBit) ? leaf_boxes[order[ch.y & ~kLeafBit]] : node_boxes[ch.y];
-  BvhNode nd;
-  inflate_into(a, nd.lo0, nd.hi0);
-  inflate_into(b, nd.lo1, nd.hi1);
-  nd.ref0 = ch.x;
-  nd.ref1 = ch.y;
-  nd._pad[0] = nd._pad[1] = 0;
-  nodes[i] = nd;
+  const uint32_t c[2] = {ch.x, ch.y};
+  for (int k = 0; k < 2; k++) {
+    if (c[k] & kLeafBit) {
+      add(c[k]);
+    } else {
+      const uint2 g = children[c[k]];
+      add(g.x);
+      add(g.y);
+    }
+  }
+  nodes[i] = quantize_node4(boxes, refs, count);
+  atomicAdd(emitted, 1u);
 }
 
 #define LB_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = e_; goto done; } } while (0)
@@ -246,14 +256,14 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
   uint64_t *keys_a = nullptr, *keys_b = nullptr; uint32_t *vals_a = nullptr, *vals_b = nullptr;
   uint2* children = nullptr; uint32_t *parent_int = nullptr, *parent_leaf = nullptr, *flags = nullptr;
   int* bounds = nullptr; uint32_t* max_depth = nullptr; void* sort_tmp = nullptr; size_t sort_bytes = 0;
-  uint32_t depth_h = 0;
+  uint32_t depth_h[2] = {0, 0};
 
   LB_CHECK(hipMalloc(&tris_tmp, sizeof(TriRec) * (size_t)n));
   LB_CHECK(hipMalloc(&out->tris, sizeof(TriRec) * (size_t)n));
   LB_CHECK(hipMalloc(&leaf_boxes, sizeof(Box) * (size_t)n));
   LB_CHECK(hipMalloc(&bounds, sizeof(int) * 8));
-  LB_CHECK(hipMalloc(&max_depth, sizeof(uint32_t)));
-  LB_CHECK(hipMemsetAsync(max_depth, 0, sizeof(uint32_t), s));
+  LB_CHECK(hipMalloc(&max_depth, 2 * sizeof(uint32_t)));  // [0] max binary depth, [1] emitted 4-wide nodes
+  LB_CHECK(hipMemsetAsync(max_depth, 0, 2 * sizeof(uint32_t), s));
   hipLaunchKernelGGL(k_flatten, dim3(blocks), dim3(256), 0, s, S, instance_count, n, tris_tmp, leaf_boxes);
 
   if (n == 1) {
@@ -288,14 +298,14 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
   hipLaunchKernelGGL(k_karras, dim3(blocks), dim3(256), 0, s, keys_b, (int)n, children, parent_int, parent_leaf);
   hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, s, (int)n, children, parent_int, parent_leaf, leaf_boxes, vals_b,
                      node_boxes, flags, max_depth);
-  hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, s, (int)n, children, leaf_boxes, vals_b, node_boxes, tris_tmp,
-                     out->nodes, out->tris);
+  hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, s, (int)n, children, parent_int, leaf_boxes, vals_b, node_boxes, tris_tmp,
+                     out->nodes, out->tris, max_depth + 1);
   LB_CHECK(hipGetLastError());
-  LB_CHECK(hipMemcpyAsync(&depth_h, max_depth, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  LB_CHECK(hipMemcpyAsync(depth_h, max_depth, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   LB_CHECK(hipStreamSynchronize(s));
   out->root_ref = 0;
-  out->node_count = n - 1;
-  out->max_depth = depth_h;
+  out->node_count = depth_h[1];
+  out->max_depth = depth_h[0];
 
 done:
   (void)hipFree(tris_tmp); (void)hipFree(leaf_boxes); (void)hipFree(node_boxes); (void)hipFree(keys_a); (void)hipFree(keys_b); (void)hipFree(vals_a);

@@ -1,4 +1,4 @@
-// pt_bvh.h — ray / triangle test and BVH2 traversal (closest-hit and any-hit).
+// pt_bvh.h — ray / triangle test and 4-wide quantised-BVH traversal (closest-hit and any-hit).
 //
 // Replaces Apple's closed `intersector<triangle_data, instancing>::intersect` (kernel.metal:244-251, 293-294,
 // 511-512, 623-629; acceleration structures built at renderer_pt.cpp:244-294, 653-749).  Semantics kept:
@@ -60,7 +60,8 @@ PT_HD float slab_entry(const float lo[3], const float hi[3], vec3 o, vec3 inv, f
 // Per-lane traversal stack: the first kLdsStack entries live in LDS ([depth][lane], bank = lane), the rest spill
 // to a per-thread HBM slab (only pathological trees get there).
 constexpr int kLdsStack = 24;
-constexpr int kSpillStack = 72;  // total depth 96 >= any LBVH depth over 63-bit codes + index tie-break
+constexpr int kSpillStack = 72;  // total 96 entries: up to 3 pushes per level of a 4-wide tree that is <= 48 levels deep
+                                 // (binary LBVH depth <= 95 over 63-bit codes + index tie-break, halved by the collapse)
 
 struct TraversalStack {
   uint32_t* lds;     // &lds_stack[0][lane_in_block]
@@ -128,34 +129,128 @@ PT_HD bool trav_init(const DeviceScene& S, TravState& ts, vec3 o, vec3 d, float 
   return false;
 }
 
+// ---- node (de)quantisation ---------------------------------------------------------------------------------------
+struct Box3 { float lo[3], hi[3]; };
+
+PT_HD float node_scale(uint8_t e) { return u2f((uint32_t)e << 23); }
+
+// Builds one BvhNode from up to four exact child boxes (already inflated). Conservative by construction: every
+// quantised coordinate is checked against the very expression the traversal evaluates.
+PT_HD BvhNode quantize_node4(const Box3* boxes, const uint32_t* refs, int count) {
+  BvhNode n;
+  float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+  for (int k = 0; k < count; k++)
+    for (int a = 0; a < 3; a++) {
+      lo[a] = fminf(lo[a], boxes[k].lo[a]);
+      hi[a] = fmaxf(hi[a], boxes[k].hi[a]);
+    }
+  float scale[3];
+  for (int a = 0; a < 3; a++) {
+    n.origin[a] = lo[a];
+    // smallest power of two s with 255 * s >= extent (exponent clamped to normal floats)
+    const float need = (hi[a] - lo[a]) * (1.0f / 255.0f);
+    uint32_t e = (f2u(need) >> 23) & 0xffu;
+    if ((f2u(need) & 0x7fffffu) != 0) e += 1;
+    if (e < 1) e = 1;
+    if (e > 254) e = 254;
+    // rounding of (hi - lo) / 255 may leave 255 * s a hair short: bump until it covers
+    while (e < 254 && lo[a] + 255.0f * node_scale((uint8_t)e) < hi[a]) e += 1;
+    n.exp[a] = (uint8_t)e;
+    scale[a] = node_scale((uint8_t)e);
+  }
+  n._pad0 = 0;
+  n._pad1[0] = n._pad1[1] = 0;
+  for (int k = 0; k < 4; k++) {
+    if (k >= count) {
+      n.ref[k] = kInvalidRef;
+      for (int a = 0; a < 3; a++) { n.qlo[k][a] = 255; n.qhi[k][a] = 0; }
+      continue;
+    }
+    n.ref[k] = refs[k];
+    for (int a = 0; a < 3; a++) {
+      const float inv = 1.0f / scale[a];
+      int ql = (int)floorf((boxes[k].lo[a] - lo[a]) * inv);
+      ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+      while (ql > 0 && lo[a] + (float)ql * scale[a] > boxes[k].lo[a]) ql--;
+      int qh = (int)ceilf((boxes[k].hi[a] - lo[a]) * inv);
+      qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+      while (qh < 255 && lo[a] + (float)qh * scale[a] < boxes[k].hi[a]) qh++;
+      n.qlo[k][a] = (uint8_t)ql;
+      n.qhi[k][a] = (uint8_t)qh;
+    }
+  }
+  return n;
+}
+
+// Conservative inflation applied to every exact box before it is quantised into its parent: the slab test must
+// never cull a triangle the Moeller-Trumbore test accepts (intersection contract). 8e-6 relative is
+// ~64 ulp of the coordinate magnitude.
+PT_HD Box3 inflate_box(const Box3& b) {
+  Box3 r;
+  for (int a = 0; a < 3; a++) {
+    const float m = fmaxf(fabsf(b.lo[a]), fabsf(b.hi[a]));
+    const float eps = m * 8e-6f + 1e-30f;
+    r.lo[a] = b.lo[a] - eps;
+    r.hi[a] = b.hi[a] + eps;
+  }
+  return r;
+}
+
+// One node per call.  The node's four child slabs are evaluated in "ray space": with A = scale * inv_d and
+// B = (origin - o) * inv_d per axis, t(q) = q * A + B (3 VALU per coordinate instead of 5).  This rounds differently
+// from the builder's origin + q * scale, by a few ulp of t; the slab slack and the 8e-6 box inflation absorb that.
+// Leaf children that pass the slab test are collected first and then tested by ONE copy of the triangle code in a
+// short loop, so a wave does not serialise through four inlined copies of it.
 template <bool ANY, bool COUNT>
 PT_HD bool trav_step(const DeviceScene& S, TravState& ts, TraversalCount* cnt) {
   const BvhNode n = S.nodes[ts.cur];
   if (COUNT) cnt->nodes++;
-  float d0 = slab_entry(n.lo0, n.hi0, ts.o, ts.inv, ts.tmin, ts.best.t);
-  float d1 = slab_entry(n.lo1, n.hi1, ts.o, ts.inv, ts.tmin, ts.best.t);
-  const uint32_t r0 = n.ref0, r1 = n.ref1;
-  bool finished = false;
-  // leaves are tested on the spot; they never go on the stack
-  if (d0 >= 0.0f && (r0 & kLeafBit)) {
-    trav_leaf(S, ts, r0, ANY, &finished, COUNT ? cnt : nullptr);
-    if (finished) return true;
-    d0 = -1.0f;
+  const float ax = node_scale(n.exp[0]) * ts.inv.x, ay = node_scale(n.exp[1]) * ts.inv.y, az = node_scale(n.exp[2]) * ts.inv.z;
+  const float bx = (n.origin[0] - ts.o.x) * ts.inv.x, by = (n.origin[1] - ts.o.y) * ts.inv.y, bz = (n.origin[2] - ts.o.z) * ts.inv.z;
+  float dist[4];
+  uint32_t leaf_mask = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    float t0 = (float)n.qlo[k][0] * ax + bx, t1 = (float)n.qhi[k][0] * ax + bx;
+    float tn = fmaxf(ts.tmin, fminf(t0, t1));
+    float tf = fminf(ts.best.t, fmaxf(t0, t1));
+    t0 = (float)n.qlo[k][1] * ay + by; t1 = (float)n.qhi[k][1] * ay + by;
+    tn = fmaxf(tn, fminf(t0, t1));
+    tf = fminf(tf, fmaxf(t0, t1));
+    t0 = (float)n.qlo[k][2] * az + bz; t1 = (float)n.qhi[k][2] * az + bz;
+    tn = fmaxf(tn, fminf(t0, t1));
+    tf = fminf(tf, fmaxf(t0, t1));
+    const bool hit = n.ref[k] != kInvalidRef && tn <= tf * 1.0000005f + 1e-30f;
+    dist[k] = hit ? tn : kInf;
+    if (hit && (n.ref[k] & kLeafBit)) {
+      leaf_mask |= 1u << k;
+      dist[k] = kInf;  // leaves never go on the stack
+    }
   }
-  if (d1 >= 0.0f && (r1 & kLeafBit)) {
-    trav_leaf(S, ts, r1, ANY, &finished, COUNT ? cnt : nullptr);
+  // triangle phase: one code copy, as many iterations as this lane has candidate leaves
+  while (leaf_mask) {
+    const uint32_t k = leaf_mask & 1u ? 0u : (leaf_mask & 2u ? 1u : (leaf_mask & 4u ? 2u : 3u));
+    leaf_mask &= leaf_mask - 1u;
+    const uint32_t ref = k == 0 ? n.ref[0] : (k == 1 ? n.ref[1] : (k == 2 ? n.ref[2] : n.ref[3]));
+    bool finished = false;
+    trav_leaf(S, ts, ref, ANY, &finished, COUNT ? cnt : nullptr);
     if (finished) return true;
-    d1 = -1.0f;
   }
-  if (d0 >= 0.0f && d1 >= 0.0f) {
-    // both internal children hit: descend into the nearer, defer the farther
-    const bool first0 = d0 <= d1;
-    ts.st.push(first0 ? r1 : r0);
-    ts.cur = first0 ? r0 : r1;
-  } else if (d0 >= 0.0f) {
+  // internal children: nearest becomes `cur`, the others are pushed far-to-near
+  // (5-comparator sorting network on (dist, ref) pairs; misses carry +inf and sink to the end)
+  float d0 = dist[0], d1 = dist[1], d2 = dist[2], d3 = dist[3];
+  uint32_t r0 = n.ref[0], r1 = n.ref[1], r2 = n.ref[2], r3 = n.ref[3];
+#define PT_CSWAP(da, ra, db, rb) { const bool sw = db < da; const float td = sw ? db : da; const uint32_t tr = sw ? rb : ra; \
+                                   db = sw ? da : db; rb = sw ? ra : rb; da = td; ra = tr; }
+  PT_CSWAP(d0, r0, d1, r1) PT_CSWAP(d2, r2, d3, r3) PT_CSWAP(d0, r0, d2, r2) PT_CSWAP(d1, r1, d3, r3) PT_CSWAP(d1, r1, d2, r2)
+#undef PT_CSWAP
+  // children that fell behind the (possibly just shortened) best.t are dropped here instead of being visited
+  const float limit = fminf(ts.best.t * 1.0000005f + 1e-30f, 3.0e38f);  // finite, so the +inf of a miss never passes
+  if (d0 <= limit) {
+    if (d3 <= limit) ts.st.push(r3);
+    if (d2 <= limit) ts.st.push(r2);
+    if (d1 <= limit) ts.st.push(r1);
     ts.cur = r0;
-  } else if (d1 >= 0.0f) {
-    ts.cur = r1;
   } else {
     if (ts.st.sp == 0) return true;
     ts.cur = ts.st.pop();

@@ -39,13 +39,21 @@ struct alignas(16) TriRec {
 };
 static_assert(sizeof(TriRec) == 48, "TriRec");
 
-// BVH2 node with both child boxes inline, 64 B = 4 x dwordx4 (one 64-B half of an L2 line).
-// ref: bit31 set = leaf, low bits = index into tris[]; else index of an internal node.
+// 4-wide BVH node with child boxes quantised to 8 bits per coordinate relative to the node's own box, 64 B =
+// 4 x dwordx4 (one half of a 128-B L2 line).  The traversal kernels are bound by vector-L1 lookups,
+// so the node packs four children into the bytes a binary node needed for two.
+//   child k box:  lo_a = origin[a] + qlo[k][a] * scale[a],  hi_a = origin[a] + qhi[k][a] * scale[a]
+//   scale[a] = 2^(exp[a] - 127)  (a power of two: the product is exact, the sum rounds once — the builder
+//   quantises against exactly this expression, so the decoded box always contains the exact child box)
+//   ref: kInvalidRef = empty slot; bit31 set = leaf (index into tris[]); else index of an internal node.
 struct alignas(16) BvhNode {
-  float lo0[3], hi0[3];
-  float lo1[3], hi1[3];
-  uint32_t ref0, ref1;
-  uint32_t _pad[2];
+  float origin[3];
+  uint8_t exp[3];
+  uint8_t _pad0;
+  uint32_t ref[4];
+  uint8_t qlo[4][3];
+  uint8_t qhi[4][3];
+  uint32_t _pad1[2];
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode");
 constexpr uint32_t kLeafBit = 0x80000000u;

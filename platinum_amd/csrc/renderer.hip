@@ -20,6 +20,7 @@
 
 #include "host_scene.h"
 #include "kernels.h"
+#include "pt_bvh.h"
 
 using namespace pt;
 
@@ -393,6 +394,9 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
     (void)hipEventElapsedTime(&ms, e0, e1);
     r->bvh_ms = ms;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    // traversal stack: <= 3 pushes per 4-wide level; 4-wide depth = ceil(binary depth / 2)
+    if (((r->bvh.max_depth + 1) / 2) * 3 > (uint32_t)(kLdsStack + kSpillStack))
+      return fail(PT_ERR_UNSUPPORTED, "BVH too deep for the traversal stack (degenerate geometry: thousands of coincident triangles?)");
     S.nodes = r->bvh.nodes;
     S.tris = r->bvh.tris;
     S.root_ref = r->bvh.root_ref;

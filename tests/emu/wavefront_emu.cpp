@@ -27,44 +27,47 @@ struct Emu {
   pt_render_params params{};
 };
 
-struct Box3 { float lo[3], hi[3]; };
-
 Box3 tri_box(const TriRec& t, const vec3& v1, const vec3& v2) {
   Box3 b;
   const float* a = t.v0; const float* p1 = &v1.x; const float* p2 = &v2.x;
   for (int k = 0; k < 3; k++) { b.lo[k] = std::min(a[k], std::min(p1[k], p2[k])); b.hi[k] = std::max(a[k], std::max(p1[k], p2[k])); }
   return b;
 }
-void inflate(const Box3& b, float lo[3], float hi[3]) {
-  for (int k = 0; k < 3; k++) {
-    float m = std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k]));
-    float eps = m * 8e-6f + 1e-30f;
-    lo[k] = b.lo[k] - eps; hi[k] = b.hi[k] + eps;
-  }
-}
 
-// returns ref of the subtree over order[first, first+count); boxes[] are per ORIGINAL triangle
-uint32_t build(Emu& e, std::vector<uint32_t>& order, const std::vector<Box3>& boxes, uint32_t first, uint32_t count, Box3* out_box) {
+// Binary median-split tree first (host only), then the same even-depth collapse + quantize_node4 the GPU builder uses.
+struct BinNode { uint32_t left, right; Box3 box; };
+
+uint32_t build_bin(std::vector<BinNode>& bin, std::vector<uint32_t>& order, const std::vector<Box3>& boxes, uint32_t first, uint32_t count) {
+  if (count == 1) return kLeafBit | first;
   Box3 bb; for (int k = 0; k < 3; k++) { bb.lo[k] = 1e30f; bb.hi[k] = -1e30f; }
   for (uint32_t i = first; i < first + count; i++)
     for (int k = 0; k < 3; k++) { bb.lo[k] = std::min(bb.lo[k], boxes[order[i]].lo[k]); bb.hi[k] = std::max(bb.hi[k], boxes[order[i]].hi[k]); }
-  *out_box = bb;
-  if (count == 1) return kLeafBit | first;
   int axis = 0; float ext = -1;
   for (int k = 0; k < 3; k++) if (bb.hi[k] - bb.lo[k] > ext) { ext = bb.hi[k] - bb.lo[k]; axis = k; }
   uint32_t mid = first + count / 2;
   std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count, [&](uint32_t a, uint32_t b) {
     return boxes[a].lo[axis] + boxes[a].hi[axis] < boxes[b].lo[axis] + boxes[b].hi[axis]; });
-  uint32_t idx = (uint32_t)e.nodes.size();
-  e.nodes.push_back({});
-  Box3 b0, b1;
-  uint32_t r0 = build(e, order, boxes, first, mid - first, &b0);
-  uint32_t r1 = build(e, order, boxes, mid, first + count - mid, &b1);
-  BvhNode n{};
-  inflate(b0, n.lo0, n.hi0); inflate(b1, n.lo1, n.hi1);
-  n.ref0 = r0; n.ref1 = r1;
-  e.nodes[idx] = n;
+  uint32_t idx = (uint32_t)bin.size();
+  bin.push_back({});
+  uint32_t l = build_bin(bin, order, boxes, first, mid - first);
+  uint32_t r = build_bin(bin, order, boxes, mid, first + count - mid);
+  bin[idx] = {l, r, bb};
   return idx;
+}
+
+void collapse(Emu& e, const std::vector<BinNode>& bin, const std::vector<uint32_t>& order, const std::vector<Box3>& boxes, uint32_t i) {
+  uint32_t refs[4]; Box3 bx[4]; int count = 0;
+  auto add = [&](uint32_t ref) {
+    bx[count] = inflate_box((ref & kLeafBit) ? boxes[order[ref & ~kLeafBit]] : bin[ref].box);
+    refs[count++] = ref;
+  };
+  const uint32_t c[2] = {bin[i].left, bin[i].right};
+  for (int k = 0; k < 2; k++) {
+    if (c[k] & kLeafBit) add(c[k]);
+    else { add(bin[c[k]].left); add(bin[c[k]].right); }
+  }
+  e.nodes[i] = quantize_node4(bx, refs, count);
+  for (int k = 0; k < count; k++) if (!(refs[k] & kLeafBit)) collapse(e, bin, order, boxes, refs[k]);
 }
 
 }  // namespace
@@ -107,7 +110,11 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
   std::vector<uint32_t> order(tmp.size());
   for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
   uint32_t root = kInvalidRef;
-  if (!tmp.empty()) { Box3 bb; root = build(*e, order, boxes, 0, (uint32_t)tmp.size(), &bb); }
+  if (!tmp.empty()) {
+    std::vector<BinNode> bin;
+    root = build_bin(bin, order, boxes, 0, (uint32_t)tmp.size());
+    if (!(root & kLeafBit)) { e->nodes.assign(bin.size(), BvhNode{}); collapse(*e, bin, order, boxes, root); }
+  }
   e->tris.resize(tmp.size());
   for (size_t i = 0; i < order.size(); i++) e->tris[i] = tmp[order[i]];
 
