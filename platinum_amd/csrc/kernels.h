@@ -6,21 +6,39 @@
 
 namespace pt {
 
-constexpr int kBlock = 256;  // 4 waves; traversal kernels keep a 24 KiB LDS stack slab per block
+constexpr int kBlock = 256;  // 4 waves; traversal kernels keep a 16 KiB LDS stack slab per block
 
-void launch_raygen(hipStream_t s, const DeviceScene& S, PathState st, vec4* Lbuf, BatchCounters* ctr, uint32_t first_sample,
-                   uint32_t nsamples);
-void launch_trace_closest(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, vec4* hit, BatchCounters* ctr,
-                          uint32_t bounce, uint32_t* spill, int32_t* hitlog, uint32_t log_stride, bool count, uint32_t refill);
+struct WaveStats { unsigned long long closest, shadow, shaded, paths; };  // per-wave, owner-updated, reduced by k_fold_counters
+
+// Wave-private queue segments (kernels.hip): wave w owns slots [w*seg_cap, (w+1)*seg_cap) of every queue array.
+struct Segments {
+  uint32_t* active[2];  // [state buffer][wave] live paths in the wave's segment
+  uint32_t* shadow;     // [wave] shadow rays in the wave's segment
+  WaveStats* stats;     // [wave]
+  uint32_t* table_closest;  // dense lists of non-empty chunks, (k << 16) | wave, rebuilt by k_chunk_tables
+  uint32_t* table_shadow;
+  uint32_t seg_cap;     // slots per wave (a multiple of 64)
+  uint32_t nwaves;      // grid * kBlock / 64 — identical for every kernel of a batch
+  uint32_t tile_contiguous;  // raygen: 1 = a wave owns adjacent tiles, 0 = tiles strided by nwaves (default)
+};
+
+void launch_raygen(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, vec4* Lbuf, Segments seg, BatchCounters* ctr,
+                   uint32_t first_sample, uint32_t nsamples);
+// After a producer: list the non-empty chunks of the closest-hit queue (state buffer `cur`, consumed at bounce
+// `bounce_closest`) and, if do_shadow, of the shadow queue consumed at `bounce_shadow`.
+void launch_chunk_tables(hipStream_t s, Segments seg, uint32_t cur, BatchCounters* ctr, uint32_t bounce_closest,
+                         uint32_t bounce_shadow, bool do_shadow);
+void launch_trace_closest(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, vec4* hit, Segments seg, uint32_t cur,
+                          BatchCounters* ctr, uint32_t bounce, uint32_t* spill, int32_t* hitlog, uint32_t log_stride, bool count);
 void launch_shade(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState sin, PathState sout, const vec4* hit,
-                  ShadowQueue sq, vec4* Lbuf, BatchCounters* ctr, uint32_t bounce);
-void launch_trace_shadow(hipStream_t s, uint32_t grid, const DeviceScene& S, ShadowQueue sq, vec4* Lbuf, BatchCounters* ctr,
-                         uint32_t bounce, uint32_t* spill, bool count, uint32_t refill);
+                  ShadowQueue sq, vec4* Lbuf, Segments seg, uint32_t cur, BatchCounters* ctr, uint32_t bounce);
+void launch_trace_shadow(hipStream_t s, uint32_t grid, const DeviceScene& S, ShadowQueue sq, vec4* Lbuf, Segments seg,
+                         BatchCounters* ctr, uint32_t bounce, uint32_t* spill, bool count);
 void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npixels, uint32_t nsamples, uint32_t n0,
                        uint32_t nonfinite_policy, BatchCounters* ctr);
-void launch_fold_counters(hipStream_t s, const BatchCounters* ctr, Totals* tot, uint32_t max_bounces, bool counted);
-void launch_hit_records(hipStream_t s, const DeviceScene& S, PathState st, const vec4* hit, const BatchCounters* ctr,
-                        pt_hit_record* out, uint32_t npixels);
+void launch_fold_counters(hipStream_t s, const BatchCounters* ctr, Totals* tot, Segments seg, bool counted);
+void launch_hit_records(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, const vec4* hit, Segments seg,
+                        pt_hit_record* out);
 
 // ---- LBVH (lbvh.hip) ----
 struct LbvhResult {

@@ -2,10 +2,22 @@
 //
 // One batch = `nsamples` samples of every pixel traced together.  Per bounce b:
 //     k_trace_closest(b)  ->  k_shade(b)  ->  k_trace_shadow(b)
-// preceded by k_raygen and followed by k_accumulate.  All kernels are stream-ordered; queue sizes never visit
-// the host: they live in BatchCounters and every kernel is a persistent grid whose waves pull 64-path chunks
-// with one atomic per wave.  k_shade compacts survivors into the other PathState buffer (ballot + prefix +
-// one atomic per wave) and appends NEE shadow rays to the shadow queue the same way.
+// preceded by k_raygen and followed by k_accumulate.  All kernels are stream-ordered; queue sizes never visit the host.
+//
+// Queues are WAVE-PRIVATE SEGMENTS.  Every kernel runs the same grid (Segments::nwaves waves); wave w owns the slots
+// {seg_slot(w, r) : r < seg_cap} of every queue array (chunk-interleaved, see seg_slot) and a count per queue.  Raygen deals 8x8 pixel tiles to the waves
+// round-robin; k_shade shades a wave's own segment and compacts the survivors (ballot + mbcnt prefix) into its own
+// segment of the other state buffer, and its NEE rays into its own shadow segment.  Survivors <= inputs, so a segment
+// never overflows and NO atomic sits on the producer side.  (Round-1 measurement: with one global append counter per
+// queue, raygen and shade were pinned at the ~88 returning atomics/us one L2 address sustains — MI355X_MICROARCH.md
+// "dequeue"; raygen got 6.7x faster without it.)
+// The trace kernels consume DENSE CHUNK TABLES: after every producer, k_chunk_tables lists the non-empty 64-entry
+// chunks of all segments, wave-major (wave 0's chunks, wave 1's, ...), and the trace waves claim runs of that list
+// from one cursor (kClaim chunks per atomic).  A wave owns a few ADJACENT 8x8 pixel tiles under all samples of the
+// batch, so the rays in flight at any moment come from a small neighbourhood of the image — the BVH subtrees they
+// touch stay in L2 — there are no empty chunks to sweep, and a chunk of survivors still comes from one or two tiles.
+// Results are written in place (hit[i], Lbuf[pid]), so it does not matter which wave traces a ray.
+// Statistics are kept per wave (no atomics) and reduced by k_fold_counters.
 //
 // Compiled with -ffp-contract=off (deterministic fp32 contract, pt_math.h).
 #include <hip/hip_runtime.h>
@@ -20,93 +32,154 @@ __device__ __forceinline__ uint32_t wave_lane() { return __builtin_amdgcn_mbcnt_
 __device__ __forceinline__ uint32_t wave_prefix(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-// All 64 lanes must be active. Lane 0 grabs `n` slots from *cursor; everyone gets the base.
-__device__ __forceinline__ uint32_t wave_alloc(uint32_t* cursor, uint32_t n, uint32_t lane) {
-  uint32_t base = 0;
-  if (lane == 0 && n > 0) base = atomicAdd(cursor, n);
-  return __builtin_amdgcn_readfirstlane(base);
-}
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+__device__ __forceinline__ uint32_t wave_index() { return blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); }
+// Slot of entry r of wave w's segment.  Segments are CHUNK-INTERLEAVED: the k-th 64-entry chunk of every wave is stored
+// back to back ((k * nwaves + w) * 64), so the trace kernels, which walk the chunks in exactly that order, stream
+// through contiguous memory like a dense queue (a wave-major layout cost the closest-hit kernel 1.4x: every chunk
+// then starts a new 44 KB-strided region).
+__device__ __forceinline__ uint32_t seg_slot(uint32_t nwaves, uint32_t w, uint32_t r) { return ((r >> 6) * nwaves + w) * 64u + (r & 63u); }
+
+// ---- chunk claims for the trace kernels ------------------------------------------------------------------------------
+constexpr uint32_t kClaim = 2;  // 64-ray chunks claimed per cursor atomic
+
+struct ChunkClaims {
+  const uint32_t* __restrict__ table;   // [total] (k << 16) | w  for every non-empty chunk, wave-major
+  const uint32_t* __restrict__ counts;  // [nwaves] rays per segment
+  uint32_t* cursor;
+  uint32_t nwaves, total, lane;
+  uint32_t next_c, end_c;
+  __device__ __forceinline__ void init(const uint32_t* tab, uint32_t total_, const uint32_t* c, uint32_t* cur, const Segments& seg,
+                                       uint32_t lane_) {
+    table = tab; total = total_; counts = c; cursor = cur; nwaves = seg.nwaves; lane = lane_;
+    next_c = end_c = 0;
+  }
+  // Wave-uniform. Returns this lane's queue index, kInvalidRef for an idle lane; `done` when the list is exhausted.
+  __device__ __forceinline__ uint32_t next(bool& done) {
+    done = false;
+    if (next_c == end_c) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(cursor, kClaim);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (base >= total) { done = true; return kInvalidRef; }
+      next_c = base;
+      end_c = base + kClaim < total ? base + kClaim : total;
+    }
+    const uint32_t e = table[next_c++];
+    const uint32_t wv = e & 0xffffu, k = e >> 16;
+    const uint32_t n = counts[wv];
+    const uint32_t r = k * 64u + lane;
+    return r < n ? seg_slot(nwaves, wv, r) : kInvalidRef;
+  }
+};
+
+// Lists the non-empty chunks of every segment, wave-major.  Block 0: the closest-hit queue (state buffer `cur`);
+// block 1: the shadow queue.  One block each: an exclusive scan over <= 8192 per-wave chunk counts, then every thread
+// writes the entries of its waves.
+__global__ void __launch_bounds__(1024) k_chunk_tables(Segments seg, uint32_t cur, BatchCounters* __restrict__ ctr,
+                                                        uint32_t bounce_closest, uint32_t bounce_shadow, uint32_t do_shadow) {
+  const bool sh = blockIdx.x == 1;
+  if (sh && !do_shadow) return;
+  const uint32_t* __restrict__ counts = sh ? seg.shadow : seg.active[cur];
+  uint32_t* __restrict__ table = sh ? seg.table_shadow : seg.table_closest;
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (seg.nwaves + 1023u) / 1024u;  // waves per thread (<= 8)
+  const uint32_t w0 = threadIdx.x * per;
+  uint32_t mine = 0;
+  for (uint32_t i = 0; i < per; i++) {
+    const uint32_t w = w0 + i;
+    if (w < seg.nwaves) mine += (counts[w] + 63u) / 64u;
+  }
+  part[threadIdx.x] = mine;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t d = part[threadIdx.x] - mine;  // exclusive prefix
+  for (uint32_t i = 0; i < per; i++) {
+    const uint32_t w = w0 + i;
+    if (w >= seg.nwaves) break;
+    const uint32_t nc = (counts[w] + 63u) / 64u;
+    for (uint32_t k = 0; k < nc; k++) table[d++] = (k << 16) | w;
+  }
+  if (threadIdx.x == 1023) {
+    if (sh) ctr->chunks_shadow[bounce_shadow] = part[1023];
+    else ctr->chunks_closest[bounce_closest] = part[1023];
+  }
+}
 
 // ---- raygen ------------------------------------------------------------------------------------------------------
-// Threads cover `nsamples` copies of the image padded to 8x8 tiles; one wave = one tile of one sample, so a wave's
-// camera rays are a coherent 8x8 bundle.  Valid lanes are compacted into queue 0.
-__global__ void __launch_bounds__(kBlock) k_raygen(DeviceScene S, PathState st, vec4* __restrict__ Lbuf,
+// One 8x8 pixel tile of one sample per wave iteration (a coherent camera-ray bundle).  Lanes outside the image
+// (partial edge tiles) are squeezed out.
+__global__ void __launch_bounds__(kBlock) k_raygen(DeviceScene S, PathState st, vec4* __restrict__ Lbuf, Segments seg,
                                                     BatchCounters* __restrict__ ctr, uint32_t first_sample,
                                                     uint32_t nsamples, uint32_t tilesX, uint32_t tilesY) {
   const uint32_t lane = wave_lane();
-  const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t w = wave_index();
   const uint32_t tiles = tilesX * tilesY;
-  const uint64_t wave_id = gid >> 6;
-  const uint32_t s = (uint32_t)(wave_id / tiles);
-  const uint32_t tile = (uint32_t)(wave_id % tiles);
-  const uint32_t x = (tile % tilesX) * 8 + (lane & 7);
-  const uint32_t y = (tile / tilesX) * 8 + (lane >> 3);
-  const bool valid = s < nsamples && x < S.width && y < S.height;
-
-  RayGenOut rg;
-  if (valid) rg = stage_raygen(S, x, y, first_sample + s);
-
-  const unsigned long long m = __ballot(valid);
-  const uint32_t base = wave_alloc(&ctr->active[0], (uint32_t)__popcll(m), lane);
-  if (valid) {
-    const uint32_t j = base + wave_prefix(m);
-    const uint32_t pid = s * (S.width * S.height) + y * S.width + x;
-    st.rayO[j] = vec4{rg.o.x, rg.o.y, rg.o.z, 0.0f};
-    st.rayD[j] = vec4{rg.d.x, rg.d.y, rg.d.z, u2f(rg.dim & kMetaDimMask)};
-    st.att[j] = vec4{1.0f, 1.0f, 1.0f, u2f(rg.offset)};
-    st.pid[j] = pid;
-    Lbuf[pid] = vec4{0.0f, 0.0f, 0.0f, 1.0f};
+  // Wave w owns tiles w, w + nwaves, w + 2 nwaves, ... under all samples of the batch (tile-major, sample-minor): its
+  // consecutive chunks are the same 8x8 pixels under successive samples, so a chunk of survivors still comes from one
+  // or two image tiles, and because the tiles of one wave are spread over the image every wave carries a statistically
+  // similar load through k_shade (which is static per wave).
+  const uint32_t per_wave = (tiles + seg.nwaves - 1) / seg.nwaves;
+  uint32_t n_out = 0;
+  for (uint32_t k = 0; k < per_wave * nsamples; k++) {
+    const uint32_t tile = seg.tile_contiguous ? w * per_wave + k / nsamples : (k / nsamples) * seg.nwaves + w;
+    const uint32_t s = k % nsamples;
+    if (tile >= tiles) break;  // wave-uniform
+    const uint32_t ty = tile / tilesX;
+    const uint32_t x = (tile - ty * tilesX) * 8 + (lane & 7);
+    const uint32_t y = ty * 8 + (lane >> 3);
+    const bool valid = x < S.width && y < S.height;
+    RayGenOut rg;
+    if (valid) rg = stage_raygen(S, x, y, first_sample + s);
+    const unsigned long long m = __ballot(valid);
+    if (valid) {
+      const uint32_t j = seg_slot(seg.nwaves, w, n_out + wave_prefix(m));
+      const uint32_t pid = s * (S.width * S.height) + y * S.width + x;
+      st.rayO[j] = vec4{rg.o.x, rg.o.y, rg.o.z, 0.0f};
+      st.rayD[j] = vec4{rg.d.x, rg.d.y, rg.d.z, u2f(rg.dim & kMetaDimMask)};
+      st.att[j] = vec4{1.0f, 1.0f, 1.0f, u2f(rg.offset)};
+      st.pid[j] = pid;
+      Lbuf[pid] = vec4{0.0f, 0.0f, 0.0f, 1.0f};
+    }
+    n_out += (uint32_t)__popcll(m);
+  }
+  if (lane == 0) {
+    seg.active[0][w] = n_out;
+    WaveStats& ws = seg.stats[w];
+    ws.paths += n_out;
+    ws.closest += n_out;
   }
 }
 
-// ---- traversal kernels: persistent waves with per-lane ray replacement ---------------------------------------------
-// A wave keeps up to 64 rays in flight.  Whenever fewer than `refill_threshold` lanes still hold a ray (and the queue is
-// not exhausted) the wave leaves the traversal loop, idle lanes pull new rays (ballot + one atomic per wave) and
-// everybody resumes where they were: a lane's traversal state (TravState + its LDS stack column) survives the refill.
-// This removes the "whole wave waits for its slowest ray" tail of a plain persistent loop.
-
-struct WaveQueue {
-  uint32_t* cursor;
-  uint32_t count;
-  bool exhausted;
-};
-// Idle lanes (need == true) get the index of a fresh queue entry, or kInvalidRef when the queue ran dry.
-__device__ __forceinline__ uint32_t wave_refill(WaveQueue& q, bool need, uint32_t lane) {
-  uint32_t idx = kInvalidRef;
-  if (q.exhausted) return idx;
-  const unsigned long long m = __ballot(need);
-  const uint32_t n = (uint32_t)__popcll(m);
-  if (n == 0) return idx;
-  const uint32_t base = wave_alloc(q.cursor, n, lane);
-  if (need) {
-    const uint32_t i = base + wave_prefix(m);
-    if (i < q.count) idx = i;
-  }
-  if (base + n >= q.count) q.exhausted = true;
-  return idx;
-}
-
+// ---- closest hit ---------------------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit,
-                                                           BatchCounters* __restrict__ ctr, uint32_t bounce,
+__global__ void __launch_bounds__(kBlock) k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments seg,
+                                                           uint32_t cur, BatchCounters* __restrict__ ctr, uint32_t bounce,
                                                            uint32_t* __restrict__ spill, int32_t* __restrict__ hitlog,
-                                                           uint32_t log_stride, uint32_t refill_threshold) {
+                                                           uint32_t log_stride) {
   __shared__ uint32_t lds_stack[kLdsStack][kBlock];
   const uint32_t lane = wave_lane();
-  WaveQueue q{&ctr->work[3 * bounce + 0], ctr->active[bounce], false};
+  ChunkClaims src;
+  src.init(seg.table_closest, ctr->chunks_closest[bounce], seg.active[cur], &ctr->work_closest[bounce], seg, lane);
   TraversalStack stack;
   stack.lds = &lds_stack[0][threadIdx.x];
   stack.lds_stride = kBlock;
   stack.spill = spill + ((size_t)blockIdx.x * kBlock + threadIdx.x);
   stack.spill_stride = gridDim.x * kBlock;
   TraversalCount tc;
-  TravState ts;
-  uint32_t ray = kInvalidRef;  // queue index of the ray this lane is tracing
 
+  // (written as an explicit init / step loop: with the whole traversal behind one call the compiler produced a kernel
+  //  1.5x slower on secondary rays)
+  TravState ts;
+  uint32_t ray = kInvalidRef;
   auto finish = [&]() {
     const RayHit& h = ts.best;
     hit[ray] = vec4{h.t, h.u, h.v, u2f(h.tri)};
@@ -118,51 +191,48 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DeviceScene S, PathSta
     }
     ray = kInvalidRef;
   };
-
   for (;;) {
-    const uint32_t fresh = wave_refill(q, ray == kInvalidRef, lane);
-    if (fresh != kInvalidRef) {
-      ray = fresh;
+    bool done;
+    ray = src.next(done);
+    if (done) break;
+    if (ray != kInvalidRef) {
       const vec4 o4 = st.rayO[ray];
       const vec4 d4 = st.rayD[ray];
       if (trav_init(S, ts, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 1e-3f, kInf, stack, false, COUNT ? &tc : nullptr)) finish();
     }
-    if (__ballot(ray != kInvalidRef) == 0) {
-      if (q.exhausted) break;
-      continue;
-    }
     while (ray != kInvalidRef) {
       if (trav_step<false, COUNT>(S, ts, &tc)) finish();
-      // lanes still in this loop vote; leave for a refill when the wave got too empty
-      if (refill_threshold && !q.exhausted && (uint32_t)__popcll(__ballot(ray != kInvalidRef)) < refill_threshold) break;
     }
   }
   if (COUNT) {
-    const uint32_t n = wave_sum(tc.nodes), t = wave_sum(tc.tris);
+    const uint32_t nn = wave_sum(tc.nodes), t = wave_sum(tc.tris);
     if (lane == 0) {
-      atomicAdd(&ctr->nodes_closest, (unsigned long long)n);
+      atomicAdd(&ctr->nodes_closest, (unsigned long long)nn);
       atomicAdd(&ctr->tris_closest, (unsigned long long)t);
     }
   }
 }
 
 // ---- shade -----------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_shade(DeviceScene S, PathState sin, PathState sout,
-                                                   const vec4* __restrict__ hit, ShadowQueue sq, vec4* __restrict__ Lbuf,
-                                                   BatchCounters* __restrict__ ctr, uint32_t bounce) {
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 2
+#endif
+__global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(DeviceScene S, PathState sin, PathState sout,
+                                                                   const vec4* __restrict__ hit, ShadowQueue sq,
+                                                                   vec4* __restrict__ Lbuf, Segments seg, uint32_t cur,
+                                                                   BatchCounters* __restrict__ ctr, uint32_t bounce) {
   const uint32_t lane = wave_lane();
-  const uint32_t count = ctr->active[bounce];
-  uint32_t* cursor = &ctr->work[3 * bounce + 1];
-  uint32_t shaded = 0;
+  const uint32_t w = wave_index();
+  const uint32_t n = seg.active[cur][w];
+  uint32_t n_out = 0, n_shadow = 0, shaded = 0;
 
-  for (;;) {
-    const uint32_t base = wave_alloc(cursor, 64, lane);
-    if (base >= count) break;
-    const uint32_t i = base + lane;
+  for (uint32_t k0 = 0; k0 < n; k0 += 64) {  // wave-uniform trip count: every lane reaches the ballots
+    const uint32_t k = k0 + lane;
+    const uint32_t i = seg_slot(seg.nwaves, w, k);
     bool alive = false, shadow = false;
     ShadeOut out;
     uint32_t pid = 0, offset = 0;
-    if (i < count) {
+    if (k < n) {
       const vec4 h4 = hit[i];
       const uint32_t tri = f2u(h4.w);
       if (tri != kInvalidRef) {  // a miss adds attenuation * backgroundColor (= 0, defs.metal:21) and ends the path
@@ -194,53 +264,62 @@ __global__ void __launch_bounds__(kBlock) k_shade(DeviceScene S, PathState sin, 
         }
       }
     }
-    // survivors -> next bounce's queue
+    // survivors -> this wave's segment of the next bounce's queue
     {
       const unsigned long long m = __ballot(alive);
-      const uint32_t b = wave_alloc(&ctr->active[bounce + 1], (uint32_t)__popcll(m), lane);
       if (alive) {
-        const uint32_t j = b + wave_prefix(m);
+        const uint32_t j = seg_slot(seg.nwaves, w, n_out + wave_prefix(m));
         sout.rayO[j] = vec4{out.next_o.x, out.next_o.y, out.next_o.z, out.next_pdf};
         sout.rayD[j] = vec4{out.next_d.x, out.next_d.y, out.next_d.z,
                             u2f((out.dim & kMetaDimMask) | (out.next_specular ? kMetaSpecular : 0u))};
         sout.att[j] = vec4{out.next_att.x, out.next_att.y, out.next_att.z, u2f(offset)};
         sout.pid[j] = pid;
       }
+      n_out += (uint32_t)__popcll(m);
     }
-    // NEE shadow rays
+    // NEE shadow rays -> this wave's shadow segment
     {
       const unsigned long long m = __ballot(shadow);
-      const uint32_t b = wave_alloc(&ctr->shadow[bounce], (uint32_t)__popcll(m), lane);
       if (shadow) {
-        const uint32_t j = b + wave_prefix(m);
+        const uint32_t j = seg_slot(seg.nwaves, w, n_shadow + wave_prefix(m));
         sq.o[j] = vec4{out.shadow_o.x, out.shadow_o.y, out.shadow_o.z, out.shadow_tmax};
         sq.d[j] = vec4{out.shadow_d.x, out.shadow_d.y, out.shadow_d.z, u2f(pid)};
         sq.contrib[j] = vec4{out.shadow_contrib.x, out.shadow_contrib.y, out.shadow_contrib.z, 0.0f};
       }
+      n_shadow += (uint32_t)__popcll(m);
     }
   }
-  const uint32_t n = wave_sum(shaded);
-  if (lane == 0 && n) atomicAdd(&ctr->shaded, n);
+  const uint32_t ns = wave_sum(shaded);
+  if (lane == 0) {
+    seg.active[cur ^ 1][w] = n_out;
+    seg.shadow[w] = n_shadow;
+    WaveStats& ws = seg.stats[w];
+    ws.closest += n_out;
+    ws.shadow += n_shadow;
+    ws.shaded += ns;
+  }
 }
 
 // ---- shadow (any hit) --------------------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf,
+__global__ void __launch_bounds__(kBlock) k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments seg,
                                                           BatchCounters* __restrict__ ctr, uint32_t bounce,
-                                                          uint32_t* __restrict__ spill, uint32_t refill_threshold) {
+                                                          uint32_t* __restrict__ spill) {
   __shared__ uint32_t lds_stack[kLdsStack][kBlock];
   const uint32_t lane = wave_lane();
-  WaveQueue q{&ctr->work[3 * bounce + 2], ctr->shadow[bounce], false};
+  ChunkClaims src;
+  src.init(seg.table_shadow, ctr->chunks_shadow[bounce], seg.shadow, &ctr->work_shadow[bounce], seg, lane);
   TraversalStack stack;
   stack.lds = &lds_stack[0][threadIdx.x];
   stack.lds_stride = kBlock;
   stack.spill = spill + ((size_t)blockIdx.x * kBlock + threadIdx.x);
   stack.spill_stride = gridDim.x * kBlock;
   TraversalCount tc;
-  TravState ts;
-  uint32_t ray = kInvalidRef;
-  uint32_t pid = 0;
 
+  // (written as an explicit init / step loop: with the whole traversal behind one call the compiler produced a kernel
+  //  1.5x slower on secondary rays)
+  TravState ts;
+  uint32_t ray = kInvalidRef, pid = 0;
   auto finish = [&]() {
     if (ts.best.tri == kInvalidRef) {  // unoccluded: L += attenuation * Ld (kernel.metal:631-637)
       const vec4 c = sq.contrib[ray];
@@ -250,29 +329,24 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow(DeviceScene S, ShadowQu
     }
     ray = kInvalidRef;
   };
-
   for (;;) {
-    const uint32_t fresh = wave_refill(q, ray == kInvalidRef, lane);
-    if (fresh != kInvalidRef) {
-      ray = fresh;
+    bool done;
+    ray = src.next(done);
+    if (done) break;
+    if (ray != kInvalidRef) {
       const vec4 o4 = sq.o[ray];
       const vec4 d4 = sq.d[ray];
       pid = f2u(d4.w);
       if (trav_init(S, ts, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 1e-3f, o4.w, stack, true, COUNT ? &tc : nullptr)) finish();
     }
-    if (__ballot(ray != kInvalidRef) == 0) {
-      if (q.exhausted) break;
-      continue;
-    }
     while (ray != kInvalidRef) {
       if (trav_step<true, COUNT>(S, ts, &tc)) finish();
-      if (refill_threshold && !q.exhausted && (uint32_t)__popcll(__ballot(ray != kInvalidRef)) < refill_threshold) break;
     }
   }
   if (COUNT) {
-    const uint32_t n = wave_sum(tc.nodes), t = wave_sum(tc.tris);
+    const uint32_t nn = wave_sum(tc.nodes), t = wave_sum(tc.tris);
     if (lane == 0) {
-      atomicAdd(&ctr->nodes_shadow, (unsigned long long)n);
+      atomicAdd(&ctr->nodes_shadow, (unsigned long long)nn);
       atomicAdd(&ctr->tris_shadow, (unsigned long long)t);
     }
   }
@@ -303,83 +377,96 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(vec4* __restrict__ acc, c
 }
 
 // ---- bookkeeping --------------------------------------------------------------------------------------------------------
-__global__ void k_fold_counters(const BatchCounters* __restrict__ ctr, Totals* __restrict__ tot, uint32_t max_bounces,
-                                uint32_t counted) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  unsigned long long closest = 0, shadow = 0;
-  for (uint32_t b = 0; b < max_bounces; b++) {
-    closest += ctr->active[b];
-    shadow += ctr->shadow[b];
+__global__ void __launch_bounds__(kBlock) k_fold_counters(const BatchCounters* __restrict__ ctr, Totals* __restrict__ tot,
+                                                           Segments seg, uint32_t counted) {
+  // one block: reduce the per-wave statistics, then clear them for the next batch
+  __shared__ unsigned long long red[4][kBlock];
+  unsigned long long a[4] = {0, 0, 0, 0};
+  for (uint32_t w = threadIdx.x; w < seg.nwaves; w += kBlock) {
+    WaveStats& ws = seg.stats[w];
+    a[0] += ws.closest; a[1] += ws.shadow; a[2] += ws.shaded; a[3] += ws.paths;
+    ws.closest = 0; ws.shadow = 0; ws.shaded = 0; ws.paths = 0;
   }
+  for (int k = 0; k < 4; k++) red[k][threadIdx.x] = a[k];
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  unsigned long long t[4] = {0, 0, 0, 0};
+  for (int k = 0; k < 4; k++)
+    for (int i = 0; i < kBlock; i++) t[k] += red[k][i];
   if (!counted) {
-    tot->closest_rays += closest;
-    tot->shadow_rays += shadow;
-    tot->shaded_hits += ctr->shaded;
-    tot->paths += ctr->active[0];
+    tot->closest_rays += t[0];
+    tot->shadow_rays += t[1];
+    tot->shaded_hits += t[2];
+    tot->paths += t[3];
     tot->nonfinite += ctr->nonfinite;
   } else {  // instrumented sample (pt_measure_traversal): only feeds the per-ray fetch averages
     tot->nodes_closest += ctr->nodes_closest; tot->tris_closest += ctr->tris_closest;
     tot->nodes_shadow += ctr->nodes_shadow; tot->tris_shadow += ctr->tris_shadow;
-    tot->counted_closest += closest; tot->counted_shadow += shadow;
+    tot->counted_closest += t[0]; tot->counted_shadow += t[1];
   }
 }
 
-// primary-ray records for pt_trace_primary: queue order -> pixel order
-__global__ void __launch_bounds__(kBlock) k_hit_records(DeviceScene S, PathState st, const vec4* __restrict__ hit,
-                                                         const BatchCounters* __restrict__ ctr,
+// primary-ray records for pt_trace_primary: segment order -> pixel order
+__global__ void __launch_bounds__(kBlock) k_hit_records(DeviceScene S, PathState st, const vec4* __restrict__ hit, Segments seg,
                                                          pt_hit_record* __restrict__ out) {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= ctr->active[0]) return;
-  const vec4 h = hit[i];
-  const uint32_t tri = f2u(h.w);
-  pt_hit_record r;
-  if (tri != kInvalidRef) {
-    r.t = h.x; r.u = h.y; r.v = h.z;
-    r.instance = (int32_t)S.tris[tri].inst;
-    r.primitive = (int32_t)S.tris[tri].prim;
-  } else {
-    r.t = 0.0f; r.u = 0.0f; r.v = 0.0f; r.instance = -1; r.primitive = -1;
+  const uint32_t lane = wave_lane();
+  const uint32_t w = wave_index();
+  const uint32_t n = seg.active[0][w];
+  for (uint32_t k = lane; k < n; k += 64) {
+    const uint32_t i = seg_slot(seg.nwaves, w, k);
+    const vec4 h = hit[i];
+    const uint32_t tri = f2u(h.w);
+    pt_hit_record r;
+    if (tri != kInvalidRef) {
+      r.t = h.x; r.u = h.y; r.v = h.z;
+      r.instance = (int32_t)S.tris[tri].inst;
+      r.primitive = (int32_t)S.tris[tri].prim;
+    } else {
+      r.t = 0.0f; r.u = 0.0f; r.v = 0.0f; r.instance = -1; r.primitive = -1;
+    }
+    out[st.pid[i]] = r;
   }
-  out[st.pid[i]] = r;
 }
 
 // ---- launchers (host) ---------------------------------------------------------------------------------------------------
-void launch_raygen(hipStream_t s, const DeviceScene& S, PathState st, vec4* Lbuf, BatchCounters* ctr, uint32_t first_sample,
-                   uint32_t nsamples) {
+void launch_raygen(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, vec4* Lbuf, Segments seg, BatchCounters* ctr,
+                   uint32_t first_sample, uint32_t nsamples) {
   const uint32_t tilesX = (S.width + 7) / 8, tilesY = (S.height + 7) / 8;
-  const uint64_t threads = (uint64_t)nsamples * tilesX * tilesY * 64;
-  const uint32_t grid = (uint32_t)((threads + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, s, S, st, Lbuf, ctr, first_sample, nsamples, tilesX, tilesY);
+  hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(kBlock), 0, s, S, st, Lbuf, seg, ctr, first_sample, nsamples, tilesX, tilesY);
 }
-void launch_trace_closest(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, vec4* hit, BatchCounters* ctr,
-                          uint32_t bounce, uint32_t* spill, int32_t* hitlog, uint32_t log_stride, bool count, uint32_t refill) {
+void launch_chunk_tables(hipStream_t s, Segments seg, uint32_t cur, BatchCounters* ctr, uint32_t bounce_closest,
+                         uint32_t bounce_shadow, bool do_shadow) {
+  hipLaunchKernelGGL(k_chunk_tables, dim3(2), dim3(1024), 0, s, seg, cur, ctr, bounce_closest, bounce_shadow, do_shadow ? 1u : 0u);
+}
+void launch_trace_closest(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, vec4* hit, Segments seg, uint32_t cur,
+                          BatchCounters* ctr, uint32_t bounce, uint32_t* spill, int32_t* hitlog, uint32_t log_stride, bool count) {
   if (count)
-    hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(kBlock), 0, s, S, st, hit, ctr, bounce, spill, hitlog, log_stride, refill);
+    hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(kBlock), 0, s, S, st, hit, seg, cur, ctr, bounce, spill, hitlog, log_stride);
   else
-    hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(kBlock), 0, s, S, st, hit, ctr, bounce, spill, hitlog, log_stride, refill);
+    hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(kBlock), 0, s, S, st, hit, seg, cur, ctr, bounce, spill, hitlog, log_stride);
 }
 void launch_shade(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState sin, PathState sout, const vec4* hit,
-                  ShadowQueue sq, vec4* Lbuf, BatchCounters* ctr, uint32_t bounce) {
-  hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, s, S, sin, sout, hit, sq, Lbuf, ctr, bounce);
+                  ShadowQueue sq, vec4* Lbuf, Segments seg, uint32_t cur, BatchCounters* ctr, uint32_t bounce) {
+  hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, s, S, sin, sout, hit, sq, Lbuf, seg, cur, ctr, bounce);
 }
-void launch_trace_shadow(hipStream_t s, uint32_t grid, const DeviceScene& S, ShadowQueue sq, vec4* Lbuf, BatchCounters* ctr,
-                         uint32_t bounce, uint32_t* spill, bool count, uint32_t refill) {
+void launch_trace_shadow(hipStream_t s, uint32_t grid, const DeviceScene& S, ShadowQueue sq, vec4* Lbuf, Segments seg,
+                         BatchCounters* ctr, uint32_t bounce, uint32_t* spill, bool count) {
   if (count)
-    hipLaunchKernelGGL(k_trace_shadow<true>, dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, ctr, bounce, spill, refill);
+    hipLaunchKernelGGL(k_trace_shadow<true>, dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, seg, ctr, bounce, spill);
   else
-    hipLaunchKernelGGL(k_trace_shadow<false>, dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, ctr, bounce, spill, refill);
+    hipLaunchKernelGGL(k_trace_shadow<false>, dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, seg, ctr, bounce, spill);
 }
 void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npixels, uint32_t nsamples, uint32_t n0,
                        uint32_t nonfinite_policy, BatchCounters* ctr) {
   hipLaunchKernelGGL(k_accumulate, dim3((npixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, acc, Lbuf, npixels, nsamples, n0,
                      nonfinite_policy, ctr);
 }
-void launch_fold_counters(hipStream_t s, const BatchCounters* ctr, Totals* tot, uint32_t max_bounces, bool counted) {
-  hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, s, ctr, tot, max_bounces, counted ? 1u : 0u);
+void launch_fold_counters(hipStream_t s, const BatchCounters* ctr, Totals* tot, Segments seg, bool counted) {
+  hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(kBlock), 0, s, ctr, tot, seg, counted ? 1u : 0u);
 }
-void launch_hit_records(hipStream_t s, const DeviceScene& S, PathState st, const vec4* hit, const BatchCounters* ctr,
-                        pt_hit_record* out, uint32_t npixels) {
-  hipLaunchKernelGGL(k_hit_records, dim3((npixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, S, st, hit, ctr, out);
+void launch_hit_records(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, const vec4* hit, Segments seg,
+                        pt_hit_record* out) {
+  hipLaunchKernelGGL(k_hit_records, dim3(grid), dim3(kBlock), 0, s, S, st, hit, seg, out);
 }
 
 }  // namespace pt

@@ -59,8 +59,8 @@ PT_HD float slab_entry(const float lo[3], const float hi[3], vec3 o, vec3 inv, f
 
 // Per-lane traversal stack: the first kLdsStack entries live in LDS ([depth][lane], bank = lane), the rest spill
 // to a per-thread HBM slab (only pathological trees get there).
-constexpr int kLdsStack = 24;
-constexpr int kSpillStack = 72;  // total 96 entries: up to 3 pushes per level of a 4-wide tree that is <= 48 levels deep
+constexpr int kLdsStack = 16;
+constexpr int kSpillStack = 80;  // total 96 entries: up to 3 pushes per level of a 4-wide tree that is <= 48 levels deep
                                  // (binary LBVH depth <= 95 over 63-bit codes + index tie-break, halved by the collapse)
 
 struct TraversalStack {

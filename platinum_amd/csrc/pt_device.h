@@ -60,10 +60,16 @@ constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kInvalidRef = 0xffffffffu;
 
 // ---- sampler table: one entry per Halton dimension (defs.metal:115-194 holds the 620 primes) ---------------------
+// 32-bit integer multiplies are quarter rate on CDNA, so the radical inverse peels `digits` base-`prime` digits per
+// 64-bit magic division (by chunk = prime^digits < 2^16) and splits the < 2^16 remainder with exact fp32 arithmetic.
 struct alignas(16) HaltonEntry {
+  uint32_t chunk;               // prime^digits, < 2^16
+  uint32_t magic_hi, magic_lo;  // M = floor((2^64-1)/chunk) + 1 ; q = (M * n) >> 64 is exact for 32-bit n
+  float inv;                    // 1.0f / (float)prime  (the reference's invB, samplers.metal:172)
+  float primef;                 // (float)prime
+  uint32_t digits;              // digits peeled per chunk (1 for primes >= 257)
   uint32_t prime;
-  uint32_t magic_hi, magic_lo;  // M = floor((2^64-1)/prime) + 1 ; q = (M * n) >> 64 is exact for 32-bit n
-  float inv;                    // 1.0f / (float)prime
+  uint32_t _pad;
 };
 constexpr int kHaltonDims = 620;
 
@@ -120,11 +126,12 @@ struct ShadowQueue {
   vec4* contrib;  // attenuation * Ld (kernel.metal:631-637), added to the path's radiance if unoccluded
 };
 
-// Per-batch device counters (zeroed by one memset per batch).
+// Per-batch device counters (zeroed by one memset per batch): trace-kernel cursors and the longest segment per queue.
 struct BatchCounters {
-  uint32_t active[64];    // active[b]  = live paths entering bounce b          (b <= 50)
-  uint32_t shadow[64];    // shadow[b]  = shadow rays queued at bounce b
-  uint32_t work[192];     // dynamic-fetch cursors: [3*b + {0 closest, 1 shade, 2 shadow}]
+  uint32_t chunks_closest[64];  // non-empty closest-hit chunks entering bounce b   (b <= 50)
+  uint32_t chunks_shadow[64];   // non-empty shadow chunks at bounce b
+  uint32_t work_closest[64];  // ordered-claim cursors of the trace kernels
+  uint32_t work_shadow[64];
   uint32_t shaded;        // hits shaded
   uint32_t nonfinite;     // samples with NaN/inf radiance seen by k_accumulate
   uint32_t _pad[2];

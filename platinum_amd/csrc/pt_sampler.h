@@ -3,8 +3,8 @@
 //   HaltonSampler             samplers.metal:154-184 (ctor, sample1d, sample2d, halton)
 //   sampleDisk / Polar / CosineHemisphere / TriUniform   samplers.metal:200-238
 // The radical inverse keeps the reference's float sequence (f *= 1/b; r += f * digit) exactly; only the integer
-// i / b and i % b are strength-reduced to a 64-bit multiply-high with a per-dimension magic number
-// (HaltonEntry), which is exact for every 32-bit i.
+// i / b and i % b are strength-reduced: one 64-bit multiply-high per chunk of digits (HaltonEntry) + exact fp32 digit
+// splitting, identical digits for every 32-bit i.
 #pragma once
 #include "pt_device.h"
 
@@ -30,12 +30,24 @@ PT_HD float halton(const HaltonEntry* __restrict__ tab, uint32_t i, uint32_t d) 
   float f = 1.0f;
   float r = 0.0f;
   while (i > 0) {
-    f = f * e.inv;
-    // q = i / prime via (M * i) >> 64, M = magic_hi:magic_lo
-    uint64_t t = (uint64_t)e.magic_hi * i + (((uint64_t)e.magic_lo * i) >> 32);
-    uint32_t q = (uint32_t)(t >> 32);
-    uint32_t digit = i - q * e.prime;
-    r = r + f * (float)digit;
+    // q = i / chunk via (M * i) >> 64, M = magic_hi:magic_lo ; rem = i % chunk holds `digits` base-prime digits
+    const uint64_t t = (uint64_t)e.magic_hi * i + (((uint64_t)e.magic_lo * i) >> 32);
+    const uint32_t q = (uint32_t)(t >> 32);
+    float rem = (float)(i - q * e.chunk);  // < 2^16: exact
+    if (e.digits == 1) {
+      f = f * e.inv;
+      r = r + f * rem;
+    } else {
+      // rem / prime for rem < 2^16: floor((rem + 0.5) * inv) is exact (|error| <= 2^-7 / prime < 0.5 / prime).
+      // Leading zero digits of the last chunk add f * 0 = 0 to r, exactly like not visiting them.
+      for (uint32_t j = 0; j < e.digits; j++) {
+        const float qf = floorf((rem + 0.5f) * e.inv);
+        const float digit = rem - qf * e.primef;
+        f = f * e.inv;
+        r = r + f * digit;
+        rem = qf;
+      }
+    }
     i = q;
   }
   return fminf(r, kOneMinusEpsilon);

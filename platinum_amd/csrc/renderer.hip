@@ -104,12 +104,14 @@ struct pt_renderer {
   uint32_t samples_in_flight = 0;
   size_t capacity = 0;  // path slots
   DevBuf<vec4> st_rayO[2], st_rayD[2], st_att[2], hit, sq_o, sq_d, sq_c, Lbuf, acc_own;
-  DevBuf<uint32_t> st_pid[2], spill;
+  DevBuf<uint32_t> st_pid[2], spill, seg_active[2], seg_shadow;
+  DevBuf<WaveStats> wave_stats;
+  DevBuf<uint32_t> chunk_table[2];
+  uint32_t nwaves = 0, seg_cap = 0, blocks_per_cu = 6, tile_contiguous = 0;
   DevBuf<BatchCounters> ctr;
   DevBuf<Totals> totals;
   vec4* acc = nullptr;
   uint32_t grid = 0;
-  uint32_t refill_threshold = 0;  // traversal: refill a wave when fewer lanes than this hold a ray (0 = never)
 
   // progress (renderer_pt.hpp:168-171)
   uint64_t accumulated = 0, total = 0;
@@ -125,6 +127,7 @@ struct pt_renderer {
 
   PathState path_state(int k) { return PathState{st_rayO[k].p, st_rayD[k].p, st_att[k].p, st_pid[k].p}; }
   ShadowQueue shadow_queue() { return ShadowQueue{sq_o.p, sq_d.p, sq_c.p}; }
+  Segments segments() { return Segments{{seg_active[0].p, seg_active[1].p}, seg_shadow.p, wave_stats.p, chunk_table[0].p, chunk_table[1].p, seg_cap, nwaves, tile_contiguous}; }
 
   void free_scene() {
     positions.release(); vdata.release(); indices.release(); slots.release(); meshes.release(); instances.release();
@@ -133,6 +136,7 @@ struct pt_renderer {
     if (bvh.tris) (void)hipFree(bvh.tris);
     bvh = LbvhResult{};
     for (int k = 0; k < 2; k++) { st_rayO[k].release(); st_rayD[k].release(); st_att[k].release(); st_pid[k].release(); }
+    seg_active[0].release(); seg_active[1].release(); seg_shadow.release(); wave_stats.release(); chunk_table[0].release(); chunk_table[1].release();
     hit.release(); sq_o.release(); sq_d.release(); sq_c.release(); Lbuf.release(); acc_own.release(); spill.release();
     acc = nullptr;
     started = false;
@@ -170,24 +174,28 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
   BatchCounters* ctr = r->ctr.p;
   PT_HIP(hipMemsetAsync(ctr, 0, sizeof(BatchCounters), s));
   const bool count = mode == BATCH_MEASURE;
+  const Segments seg = r->segments();
   {
     ScopedTimer t(r, K_RAYGEN);
-    launch_raygen(s, S, r->path_state(0), r->Lbuf.p, ctr, first, ns);
+    launch_raygen(s, r->grid, S, r->path_state(0), r->Lbuf.p, seg, ctr, first, ns);
+    launch_chunk_tables(s, seg, 0, ctr, 0, 0, false);
   }
   int cur = 0;
   const bool mis = S.integrator == PT_INTEGRATOR_MIS;
   for (uint32_t b = 0; b < S.max_bounces; b++) {
     {
       ScopedTimer t(r, K_CLOSEST);
-      launch_trace_closest(s, r->grid, S, r->path_state(cur), r->hit.p, ctr, b, r->spill.p, hitlog, S.width * S.height, count, r->refill_threshold);
+      launch_trace_closest(s, r->grid, S, r->path_state(cur), r->hit.p, seg, (uint32_t)cur, ctr, b, r->spill.p, hitlog, S.width * S.height, count);
     }
     {
       ScopedTimer t(r, K_SHADE);
-      launch_shade(s, r->grid, S, r->path_state(cur), r->path_state(cur ^ 1), r->hit.p, r->shadow_queue(), r->Lbuf.p, ctr, b);
+      launch_shade(s, r->grid, S, r->path_state(cur), r->path_state(cur ^ 1), r->hit.p, r->shadow_queue(), r->Lbuf.p, seg, (uint32_t)cur, ctr, b);
+      // closest-hit list of bounce b + 1 (written to chunks_closest[b + 1]) and shadow list of bounce b
+      launch_chunk_tables(s, seg, (uint32_t)(cur ^ 1), ctr, b + 1, b, mis);
     }
     if (mis) {
       ScopedTimer t(r, K_SHADOW);
-      launch_trace_shadow(s, r->grid, S, r->shadow_queue(), r->Lbuf.p, ctr, b, r->spill.p, count, r->refill_threshold);
+      launch_trace_shadow(s, r->grid, S, r->shadow_queue(), r->Lbuf.p, seg, ctr, b, r->spill.p, count);
     }
     cur ^= 1;
   }
@@ -195,7 +203,8 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
     ScopedTimer t(r, K_ACCUM);
     launch_accumulate(s, r->acc, r->Lbuf.p, S.width * S.height, ns, n0, r->params.nonfinite_policy, ctr);
   }
-  if (mode != BATCH_DEBUG) launch_fold_counters(s, ctr, r->totals.p, S.max_bounces, count);
+  // BATCH_DEBUG still folds (to clear the per-wave statistics) but into a scratch Totals slot
+  launch_fold_counters(s, ctr, mode == BATCH_DEBUG ? r->totals.p + 1 : r->totals.p, seg, count);
   PT_HIP(hipGetLastError());
   return PT_OK;
 }
@@ -248,8 +257,11 @@ int build_halton_table(pt_renderer* r) {
     for (uint32_t d = 2; d * d <= c; d++)
       if (c % d == 0) { prime = false; break; }
     if (!prime) continue;
-    const uint64_t M = ~0ull / c + 1;
-    tab.push_back({c, (uint32_t)(M >> 32), (uint32_t)M, 1.0f / (float)c});
+    uint32_t digits = 1;
+    uint64_t chunk = c;
+    while (chunk * c < 65536ull) { chunk *= c; digits++; }
+    const uint64_t M = ~0ull / chunk + 1;
+    tab.push_back({(uint32_t)chunk, (uint32_t)(M >> 32), (uint32_t)M, 1.0f / (float)c, (float)c, digits, c, 0u});
   }
   PT_HIP(r->halton.upload(tab));
   return PT_OK;
@@ -272,7 +284,8 @@ int pt_create(const pt_create_info* info, pt_renderer** out) {
   PT_HIP(hipSetDevice(info->device_ordinal));
   auto* r = new pt_renderer();
   r->device = info->device_ordinal;
-  if (const char* e = getenv("PTAMD_REFILL_THRESHOLD")) r->refill_threshold = (uint32_t)atoi(e);  // tuning knob
+  if (const char* e = getenv("PTAMD_TILE_CONTIGUOUS")) r->tile_contiguous = (uint32_t)atoi(e);  // tuning knobs
+  if (const char* e = getenv("PTAMD_BLOCKS_PER_CU")) r->blocks_per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, r->device) == hipSuccess) r->num_cu = prop.multiProcessorCount;
   int rc = PT_OK;
@@ -298,7 +311,7 @@ int pt_create(const pt_create_info* info, pt_renderer** out) {
     }
     if ((rc = load_luts(r, blob, size)) != PT_OK) break;
     if ((rc = build_halton_table(r)) != PT_OK) break;
-    if (r->ctr.alloc(1) != hipSuccess || r->totals.alloc(1) != hipSuccess) { rc = fail(PT_ERR_OUT_OF_MEMORY, "counter allocation failed"); break; }
+    if (r->ctr.alloc(1) != hipSuccess || r->totals.alloc(2) != hipSuccess) { rc = fail(PT_ERR_OUT_OF_MEMORY, "counter allocation failed"); break; }
   } while (0);
   if (rc != PT_OK) { pt_destroy(r); return rc; }
   *out = r;
@@ -411,16 +424,31 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
   }
   sif = std::min<uint32_t>(std::min<uint32_t>(sif, p->spp), 256);
   r->samples_in_flight = sif;
-  r->capacity = (size_t)npix * sif;
+  // wave-private queue segments: every wave of the persistent grid owns ceil(tiles / nwaves) 8x8 tiles worth of slots
+  // The grid must be fully RESIDENT for the trace kernels (a wave that starts late would serialise its whole segment
+  // behind the others): 6 blocks of 256 threads per CU fit their 16 KiB LDS slab, <= 80 VGPRs and ~96 SGPRs.
+  r->grid = (uint32_t)r->num_cu * r->blocks_per_cu;
+  r->nwaves = r->grid * (kBlock / 64);
+  {
+    const uint64_t tiles = (uint64_t)((p->width + 7) / 8) * ((p->height + 7) / 8);
+    const uint64_t per_wave = (tiles + r->nwaves - 1) / r->nwaves;  // a wave owns floor or ceil(tiles / nwaves) adjacent tiles
+    if (per_wave * sif >= 65536) return fail(PT_ERR_INVALID_ARGUMENT, "image x samples_in_flight too large for the chunk tables");
+    r->seg_cap = (uint32_t)(per_wave * sif) * 64;
+  }
+  r->capacity = (size_t)r->nwaves * r->seg_cap;  // >= npix * sif
   for (int k = 0; k < 2; k++) {
     PT_HIP(r->st_rayO[k].alloc(r->capacity)); PT_HIP(r->st_rayD[k].alloc(r->capacity));
     PT_HIP(r->st_att[k].alloc(r->capacity)); PT_HIP(r->st_pid[k].alloc(r->capacity));
   }
   PT_HIP(r->hit.alloc(r->capacity));
   PT_HIP(r->sq_o.alloc(r->capacity)); PT_HIP(r->sq_d.alloc(r->capacity)); PT_HIP(r->sq_c.alloc(r->capacity));
-  PT_HIP(r->Lbuf.alloc(r->capacity));
-  r->grid = (uint32_t)r->num_cu * 8;  // persistent grid: 8 blocks (32 waves) per CU
-  PT_HIP(r->spill.alloc((size_t)r->grid * kBlock * 72));
+  PT_HIP(r->Lbuf.alloc((size_t)npix * sif));
+  for (int k = 0; k < 2; k++) PT_HIP(r->seg_active[k].alloc(r->nwaves));
+  PT_HIP(r->seg_shadow.alloc(r->nwaves));
+  PT_HIP(r->wave_stats.alloc(r->nwaves));
+  for (int k = 0; k < 2; k++) PT_HIP(r->chunk_table[k].alloc(r->capacity / 64));
+  PT_HIP(r->spill.alloc((size_t)r->grid * kBlock * kSpillStack));  // per-thread HBM stack slab behind the LDS stack
+  PT_HIP(hipMemsetAsync(r->wave_stats.p, 0, sizeof(WaveStats) * r->nwaves, r->stream));
   if (p->external_accumulator) {
     r->acc = (vec4*)p->external_accumulator;
   } else {
@@ -520,9 +548,11 @@ int pt_trace_primary(pt_renderer* r, uint32_t sample_idx, pt_hit_record* out) {
   PT_HIP(rec.alloc(npix));
   hipStream_t s = r->stream;
   PT_HIP(hipMemsetAsync(r->ctr.p, 0, sizeof(BatchCounters), s));
-  launch_raygen(s, r->S, r->path_state(0), r->Lbuf.p, r->ctr.p, sample_idx, 1);
-  launch_trace_closest(s, r->grid, r->S, r->path_state(0), r->hit.p, r->ctr.p, 0, r->spill.p, nullptr, npix, false, r->refill_threshold);
-  launch_hit_records(s, r->S, r->path_state(0), r->hit.p, r->ctr.p, rec.p, npix);
+  launch_raygen(s, r->grid, r->S, r->path_state(0), r->Lbuf.p, r->segments(), r->ctr.p, sample_idx, 1);
+  launch_chunk_tables(s, r->segments(), 0, r->ctr.p, 0, 0, false);
+  launch_trace_closest(s, r->grid, r->S, r->path_state(0), r->hit.p, r->segments(), 0, r->ctr.p, 0, r->spill.p, nullptr, npix, false);
+  launch_hit_records(s, r->grid, r->S, r->path_state(0), r->hit.p, r->segments(), rec.p);
+  launch_fold_counters(s, r->ctr.p, r->totals.p + 1, r->segments(), false);  // clears the per-wave statistics (scratch slot)
   PT_HIP(hipGetLastError());
   PT_HIP(hipStreamSynchronize(s));
   PT_HIP(hipMemcpy(out, rec.p, sizeof(pt_hit_record) * npix, hipMemcpyDeviceToHost));

@@ -87,8 +87,11 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
     bool prime = true;
     for (uint32_t d = 2; d * d <= c; d++) if (c % d == 0) { prime = false; break; }
     if (!prime) continue;
-    uint64_t M = ~0ull / c + 1;
-    e->halton.push_back({c, (uint32_t)(M >> 32), (uint32_t)M, 1.0f / (float)c});
+    uint32_t digits = 1;
+    uint64_t chunk = c;
+    while (chunk * c < 65536ull) { chunk *= c; digits++; }
+    const uint64_t M = ~0ull / chunk + 1;
+    e->halton.push_back({(uint32_t)chunk, (uint32_t)(M >> 32), (uint32_t)M, 1.0f / (float)c, (float)c, digits, c, 0u});
   }
   // flatten to world space (same sequence as lbvh.hip k_flatten)
   std::vector<TriRec> tmp; std::vector<Box3> boxes;

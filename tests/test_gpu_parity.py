@@ -129,3 +129,38 @@ def test_full_size_properties_c2(gpu_renderer):
     assert 0.05 < m < 5.0
     st = gpu_renderer.stats()
     assert st.paths == 1920 * 1080 * 4 and st.closest_rays >= st.paths and st.triangles == 12 + 6144
+
+
+def test_million_triangle_field_parity(gpu_renderer):
+    """C3 scene at full triangle count (1 036 300 triangles, LBVH depth > 30: exercises the HBM spill part of the
+    traversal stack and the chunk tables over thousands of segments) at reduced resolution."""
+    sc = scenes.field_scene(32)
+    w, h, bounces = 256, 144, 6
+    p = _start(gpu_renderer, sc, w, h, 2, bounces)
+    st = gpu_renderer.stats()
+    assert st.triangles == 1036300 and st.bvh_max_depth >= 24
+    o = oracle_lib.OracleScene(sc, p)
+    g, c = gpu_renderer.tracePrimary(0), o.trace_primary(0)
+    assert g.tobytes() == c.tobytes()
+    rg, hg = gpu_renderer.debugSample(1)
+    rc, hc = o.debug_sample(1)
+    assert np.array_equal(hg, hc)
+    assert np.array_equal(rg.view(np.uint32), rc.view(np.uint32))
+    gpu_renderer.render(0)
+    acc = gpu_renderer.readbackAccumulator()
+    ref = o.render(0, 2)
+    assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
+    so = o.stats()
+    st = gpu_renderer.stats()
+    assert (st.closest_rays, st.shadow_rays, st.shaded_hits) == (so.closest_rays, so.shadow_rays, so.shaded_hits)
+
+
+def test_odd_image_size_and_many_batches(gpu_renderer):
+    """Image size that is not a multiple of the 8x8 raygen tile, samples_in_flight that does not divide spp."""
+    sc = _scene("cornell_sphere")
+    w, h, spp = 203, 117, 7
+    p = _start(gpu_renderer, sc, w, h, spp, 5, samples_in_flight=3)
+    gpu_renderer.render(0)
+    acc = gpu_renderer.readbackAccumulator()
+    ref = oracle_lib.OracleScene(sc, p).render(0, spp)
+    assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))

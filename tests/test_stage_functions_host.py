@@ -34,8 +34,8 @@ def test_magic_division_halton_equals_oracle():
     e = emu_lib.EmuScene(scenes.cornell_scene(), make_params(8, 8, 1, 2))
     L = oracle_lib.lib()
     rng = np.random.default_rng(11)
-    for i in [0, 1, 2, 0xFFFFFFFF, 0x80000000] + [int(v) for v in rng.integers(0, 2**32, 300)]:
-        for d in (0, 1, 2, 3, 4, 5, 11, 53, 54, 256, 257, 619):
+    for i in [0, 1, 2, 0xFFFFFFFF, 0x80000000, 65535, 65536, 59049, 59048, 14641 * 14641 - 1] + [int(v) for v in rng.integers(0, 2**32, 300)]:
+        for d in (0, 1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 13, 52, 53, 54, 55, 256, 257, 619):  # every digits-per-chunk class
             assert e.halton(i, d) == L.orc_halton(i, d), (i, d)
 
 
