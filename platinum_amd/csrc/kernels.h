@@ -19,6 +19,7 @@ struct Segments {
   uint32_t* table_shadow;
   uint32_t seg_cap;     // slots per wave (a multiple of 64)
   uint32_t nwaves;      // grid * kBlock / 64 — identical for every kernel of a batch
+  uint32_t refill_threshold; // trace kernels: refill a wave's idle lanes when fewer than this many still hold a ray (0 = only when all idle)
   uint32_t tile_contiguous;  // raygen: 1 = a wave owns adjacent tiles, 0 = tiles strided by nwaves (default)
 };
 

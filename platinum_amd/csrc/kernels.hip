@@ -57,6 +57,43 @@ struct ChunkClaims {
     table = tab; total = total_; counts = c; cursor = cur; nwaves = seg.nwaves; lane = lane_;
     next_c = end_c = 0;
   }
+  // ---- per-lane ray replacement ----
+  // The wave keeps a pool = the not yet started rays [pool_next, pool_end) of its current chunk.  Lanes whose ray has
+  // finished (need == true) take the next pool entries in lane order; an empty pool is refilled from the claim list.
+  // Wave-uniform call. Returns kInvalidRef for lanes that got nothing; `exhausted` = no chunk left anywhere.
+  uint32_t pool_next = 0, pool_end = 0;
+  bool exhausted = false;
+  __device__ __forceinline__ uint32_t take(bool need) {
+    uint32_t got = kInvalidRef;
+    for (;;) {
+      const unsigned long long m = __ballot(need && got == kInvalidRef);
+      if (m == 0) return got;
+      if (pool_next == pool_end) {
+        if (exhausted) return got;
+        if (next_c == end_c) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(cursor, kClaim);
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (base >= total) { exhausted = true; return got; }
+          next_c = base;
+          end_c = base + kClaim < total ? base + kClaim : total;
+        }
+        const uint32_t e = table[next_c++];
+        const uint32_t wv = e & 0xffffu, k = e >> 16;
+        const uint32_t n = counts[wv];
+        const uint32_t left = n - k * 64u;  // > 0: the table lists non-empty chunks only
+        pool_next = seg_slot(nwaves, wv, k * 64u);
+        pool_end = pool_next + (left < 64u ? left : 64u);
+      }
+      if (need && got == kInvalidRef) {
+        const uint32_t idx = pool_next + wave_prefix(m);
+        if (idx < pool_end) got = idx;
+      }
+      const uint32_t avail = pool_end - pool_next, want = (uint32_t)__popcll(m);
+      pool_next += want < avail ? want : avail;
+    }
+  }
+
   // Wave-uniform. Returns this lane's queue index, kInvalidRef for an idle lane; `done` when the list is exhausted.
   __device__ __forceinline__ uint32_t next(bool& done) {
     done = false;
@@ -191,17 +228,23 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DeviceScene S, PathSta
     }
     ray = kInvalidRef;
   };
+  const uint32_t refill = seg.refill_threshold;
   for (;;) {
-    bool done;
-    ray = src.next(done);
-    if (done) break;
-    if (ray != kInvalidRef) {
+    const uint32_t fresh = src.take(ray == kInvalidRef);
+    if (fresh != kInvalidRef) {
+      ray = fresh;
       const vec4 o4 = st.rayO[ray];
       const vec4 d4 = st.rayD[ray];
       if (trav_init(S, ts, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 1e-3f, kInf, stack, false, COUNT ? &tc : nullptr)) finish();
     }
+    if (__ballot(ray != kInvalidRef) == 0) {
+      if (src.exhausted && src.pool_next == src.pool_end) break;
+      continue;
+    }
     while (ray != kInvalidRef) {
       if (trav_step<false, COUNT>(S, ts, &tc)) finish();
+      // lanes still in this loop vote: leave for a refill once the wave has emptied below the threshold
+      if (refill && !src.exhausted && (uint32_t)__popcll(__ballot(ray != kInvalidRef)) < refill) break;
     }
   }
   if (COUNT) {
@@ -329,18 +372,23 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow(DeviceScene S, ShadowQu
     }
     ray = kInvalidRef;
   };
+  const uint32_t refill = seg.refill_threshold;
   for (;;) {
-    bool done;
-    ray = src.next(done);
-    if (done) break;
-    if (ray != kInvalidRef) {
+    const uint32_t fresh = src.take(ray == kInvalidRef);
+    if (fresh != kInvalidRef) {
+      ray = fresh;
       const vec4 o4 = sq.o[ray];
       const vec4 d4 = sq.d[ray];
       pid = f2u(d4.w);
       if (trav_init(S, ts, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 1e-3f, o4.w, stack, true, COUNT ? &tc : nullptr)) finish();
     }
+    if (__ballot(ray != kInvalidRef) == 0) {
+      if (src.exhausted && src.pool_next == src.pool_end) break;
+      continue;
+    }
     while (ray != kInvalidRef) {
       if (trav_step<true, COUNT>(S, ts, &tc)) finish();
+      if (refill && !src.exhausted && (uint32_t)__popcll(__ballot(ray != kInvalidRef)) < refill) break;
     }
   }
   if (COUNT) {

@@ -107,7 +107,7 @@ struct pt_renderer {
   DevBuf<uint32_t> st_pid[2], spill, seg_active[2], seg_shadow;
   DevBuf<WaveStats> wave_stats;
   DevBuf<uint32_t> chunk_table[2];
-  uint32_t nwaves = 0, seg_cap = 0, blocks_per_cu = 6, tile_contiguous = 0;
+  uint32_t nwaves = 0, seg_cap = 0, blocks_per_cu = 6, tile_contiguous = 0, refill_threshold = 48;
   DevBuf<BatchCounters> ctr;
   DevBuf<Totals> totals;
   vec4* acc = nullptr;
@@ -127,7 +127,7 @@ struct pt_renderer {
 
   PathState path_state(int k) { return PathState{st_rayO[k].p, st_rayD[k].p, st_att[k].p, st_pid[k].p}; }
   ShadowQueue shadow_queue() { return ShadowQueue{sq_o.p, sq_d.p, sq_c.p}; }
-  Segments segments() { return Segments{{seg_active[0].p, seg_active[1].p}, seg_shadow.p, wave_stats.p, chunk_table[0].p, chunk_table[1].p, seg_cap, nwaves, tile_contiguous}; }
+  Segments segments() { return Segments{{seg_active[0].p, seg_active[1].p}, seg_shadow.p, wave_stats.p, chunk_table[0].p, chunk_table[1].p, seg_cap, nwaves, refill_threshold, tile_contiguous}; }
 
   void free_scene() {
     positions.release(); vdata.release(); indices.release(); slots.release(); meshes.release(); instances.release();
@@ -284,6 +284,7 @@ int pt_create(const pt_create_info* info, pt_renderer** out) {
   PT_HIP(hipSetDevice(info->device_ordinal));
   auto* r = new pt_renderer();
   r->device = info->device_ordinal;
+  if (const char* e = getenv("PTAMD_REFILL")) r->refill_threshold = (uint32_t)atoi(e);
   if (const char* e = getenv("PTAMD_TILE_CONTIGUOUS")) r->tile_contiguous = (uint32_t)atoi(e);  // tuning knobs
   if (const char* e = getenv("PTAMD_BLOCKS_PER_CU")) r->blocks_per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));
   hipDeviceProp_t prop;
