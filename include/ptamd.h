@@ -208,7 +208,7 @@ void pt_destroy(pt_renderer* r);
 typedef struct pt_render_params {
   uint32_t width, height;      /* viewport size */
   uint32_t spp;                /* samples this renderer accumulates (m_accumulationFrames) */
-  uint32_t gmon_buckets;       /* used only with PT_FLAG_GMON; constants.gmonBuckets is 1 otherwise */
+  uint32_t gmon_buckets;       /* used only with PT_FLAG_GMON (1..32, gmon.metal:12); constants.gmonBuckets is 1 otherwise */
   int32_t flags;               /* PT_FLAG_* */
   uint32_t integrator;         /* PT_INTEGRATOR_* (default MIS, renderer_pt.hpp:98) */
   pt_colorspace working_space; /* default BT2020 (pt_viewport.hpp:95) */
@@ -235,6 +235,14 @@ int pt_wait(pt_renderer* r);
 int pt_status(const pt_renderer* r);
 int pt_progress(const pt_renderer* r, uint64_t* accumulated, uint64_t* total);
 uint64_t pt_render_time_ms(const pt_renderer* r);
+
+/* Renderer::gmonOptions() (renderer_pt.hpp:71; pt_shader_defs.hpp:164-166 GmonOptions). With PT_FLAG_GMON the samples
+ * are accumulated into `gmon_buckets` bucket images (bucket = sample / ceil(spp / buckets), renderer_pt.cpp:124-139)
+ * and the accumulator holds their Gini-weighted median-of-means (shaders/gmon.metal), recomputed after every batch. */
+typedef struct pt_gmon_options { float cap; } pt_gmon_options; /* default 1.0 */
+int pt_set_gmon_options(pt_renderer* r, const pt_gmon_options* options);
+/* One bucket image (W*H*4 floats), for parity checks. */
+int pt_read_gmon_bucket(pt_renderer* r, uint32_t bucket, float* rgba_out);
 
 /* The float accumulator: W*H RGBA32F, row-major, top-left origin, running mean, alpha 1
  * (renderer_pt.cpp:812-821, kernel.metal:672-684).  Blocks like readbackRenderTarget (:1039-1059). */

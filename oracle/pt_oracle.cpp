@@ -873,7 +873,7 @@ void update_constants(orc_scene& sc, const pt_camera& cam) {
   memset(&c, 0, sizeof(c));
   c.frameIdx = 0;
   c.spp = p.spp;
-  c.gmonBuckets = (p.flags & PT_FLAG_GMON) ? p.gmon_buckets : 1;
+  c.gmonBuckets = (p.flags & PT_FLAG_GMON) ? p.gmon_buckets : 1;  // renderer_pt.cpp:993-994
   c.lutSizeE = (uint32_t)sc.luts.E.w;
   c.lutSizeEavg = (uint32_t)sc.luts.Eavg.w;
   c.flags = p.flags;
@@ -1242,6 +1242,9 @@ int orc_get_lights(const orc_scene* sc, pt_area_light* out, uint32_t capacity, u
 int orc_render(orc_scene* sc, uint32_t first_sample, uint32_t nsamples, float* acc, uint32_t acc_n0, int threads,
                int count_traversal) {
   const uint32_t W = sc->params.width, H = sc->params.height;
+  const bool gmon = (sc->params.flags & PT_FLAG_GMON) != 0;
+  const uint32_t gbuckets = gmon ? sc->params.gmon_buckets : 1;
+  const uint32_t spb = (sc->params.spp + gbuckets - 1) / gbuckets;
   if (threads < 1) threads = 1;
   std::atomic<uint32_t> next_row{0};
   auto worker = [&]() {
@@ -1257,7 +1260,15 @@ int orc_render(orc_scene* sc, uint32_t first_sample, uint32_t nsamples, float* a
             st.nonfinite++;
             if (sc->params.nonfinite_policy == PT_NONFINITE_ZERO) L = f3(0.0f);  // build extension, see ptamd.h
           }
-          uint32_t localFrameIdx = acc_n0 + s;  // frameIdx / gmonBuckets with gmonBuckets = 1
+          // kernel.metal:675-681: localFrameIdx = frameIdx / gmonBuckets (gmonBuckets is 1 without GMoN, renderer_pt.cpp:993).
+          // With RendererFlags_GMoN the sample goes to bucket frameIdx / ceil(spp / buckets) (renderer_pt.cpp:124-139); `acc`
+          // then holds `gmon_buckets` images back to back.
+          const uint32_t f = acc_n0 + s;
+          uint32_t localFrameIdx = f;
+          if (gmon) {
+            px = &acc[4 * ((size_t)(f / spb) * W * H + (size_t)y * W + x)];
+            localFrameIdx = f / gbuckets;
+          }
           if (localFrameIdx > 0) {
             float3 L_prev = f3(px[0], px[1], px[2]);
             L += L_prev * (float)localFrameIdx;
@@ -1276,6 +1287,41 @@ int orc_render(orc_scene* sc, uint32_t first_sample, uint32_t nsamples, float* a
   worker();
   for (auto& t : pool) t.join();
   sc->n_paths += (uint64_t)W * H * nsamples;
+  return 0;
+}
+
+// shaders/gmon.metal:14-55 — resolve `nBuckets` bucket images (back to back) into `out` (W*H*4).
+int orc_gmon_resolve(const orc_scene* sc, const float* buckets, uint32_t nBuckets, float cap, float* out) {
+  const size_t npix = (size_t)sc->params.width * sc->params.height;
+  const float3 lw = f3(0.2126f, 0.7152f, 0.0722f);  // gmon.metal:10
+  for (size_t p = 0; p < npix; p++) {
+    float3 values[32];  // maxBuckets, gmon.metal:12
+    for (uint32_t i = 0; i < nBuckets; i++) {
+      const float* b = &buckets[4 * ((size_t)i * npix + p)];
+      values[i] = f3(b[0], b[1], b[2]);
+    }
+    for (uint32_t i = nBuckets; i > 1; i--)
+      for (uint32_t j = 1; j < i; j++)
+        if (dot(values[j], lw) < dot(values[j - 1], lw)) {
+          float3 temp = values[j - 1];
+          values[j - 1] = values[j];
+          values[j] = temp;
+        }
+    float3 sum = f3(0.0f), weightedSum = f3(0.0f);
+    for (uint32_t i = 0; i < nBuckets; i++) {
+      sum += values[i];
+      weightedSum += (float)(i + 1) * values[i];
+    }
+    float G = (2.0f * dot(weightedSum, lw)) / ((float)nBuckets * dot(sum, lw)) - (float)(nBuckets + 1) / (float)nBuckets;
+    G = fminf(G, cap);
+    // int(G * float(nBuckets / 2)): a NaN / negative product (black pixel) is defined as 0 here (UB in MSL)
+    const float cf = G * (float)(nBuckets / 2);
+    const int c = cf > 0.0f ? (int)cf : 0;
+    sum = f3(0.0f);
+    for (int i = c; i < (int)nBuckets - c; i++) sum += values[i];
+    float3 color = sum / (float)((int)nBuckets - 2 * c);
+    out[4 * p] = color.x; out[4 * p + 1] = color.y; out[4 * p + 2] = color.z; out[4 * p + 3] = 1.0f;
+  }
   return 0;
 }
 

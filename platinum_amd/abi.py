@@ -116,6 +116,10 @@ class RenderParams(C.Structure):
     ]
 
 
+class GmonOptions(C.Structure):
+    _fields_ = [("cap", C.c_float)]
+
+
 class HitRecord(C.Structure):
     _fields_ = [("t", C.c_float), ("u", C.c_float), ("v", C.c_float), ("instance", C.c_int32), ("primitive", C.c_int32)]
 
@@ -148,6 +152,8 @@ SYMBOLS = [
     ("pt_render_time_ms", C.c_uint64, [C.c_void_p]),
     ("pt_read_accumulator", C.c_int, [C.c_void_p, C.c_void_p]),
     ("pt_accumulator_device_ptr", C.c_void_p, [C.c_void_p]),
+    ("pt_set_gmon_options", C.c_int, [C.c_void_p, C.POINTER(GmonOptions)]),
+    ("pt_read_gmon_bucket", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     ("pt_last_error", C.c_char_p, []),
     ("pt_get_constants", C.c_int, [C.c_void_p, C.POINTER(Constants)]),
     ("pt_get_lights", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),

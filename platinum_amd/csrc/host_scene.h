@@ -184,7 +184,7 @@ inline int build_host_scene(const pt_scene_snapshot* scene, const pt_render_para
     const vec3 vu = u * vw;
     const vec3 vv = -v * vh;
     C.spp = p->spp;
-    C.gmonBuckets = 1;
+    C.gmonBuckets = (p->flags & PT_FLAG_GMON) ? p->gmon_buckets : 1;  // renderer_pt.cpp:993-994
     C.lutSizeE = lut_w_E;
     C.lutSizeEavg = lut_w_Eavg;
     C.flags = p->flags;

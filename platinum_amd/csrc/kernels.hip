@@ -424,6 +424,70 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(vec4* __restrict__ acc, c
   acc[p] = a;
 }
 
+// ---- GMoN ---------------------------------------------------------------------------------------------
+// Accumulate into the bucket images exactly as the reference does with RendererFlags_GMoN: sample f goes to bucket
+// f / ceil(spp / buckets) (renderer_pt.cpp:124-139) with the running-mean weight n = f / gmonBuckets
+// (kernel.metal:675-681 — note: NOT the sample's index inside its bucket; reproduced as is).
+__global__ void __launch_bounds__(kBlock) k_accumulate_gmon(vec4* __restrict__ buckets, const vec4* __restrict__ Lbuf,
+                                                             uint32_t npixels, uint32_t nsamples, uint32_t n0,
+                                                             uint32_t samples_per_bucket, uint32_t gmon_buckets,
+                                                             uint32_t nonfinite_policy, BatchCounters* __restrict__ ctr) {
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= npixels) return;
+  for (uint32_t s = 0; s < nsamples; s++) {
+    const vec4 L4 = Lbuf[(size_t)s * npixels + p];
+    vec3 L = v3(L4.x, L4.y, L4.z);
+    if (!(fabsf(L.x) <= 3.0e38f && fabsf(L.y) <= 3.0e38f && fabsf(L.z) <= 3.0e38f)) {
+      atomicAdd(&ctr->nonfinite, 1u);
+      if (nonfinite_policy == PT_NONFINITE_ZERO) L = v3(0.0f);
+    }
+    const uint32_t f = n0 + s;
+    vec4* acc = buckets + (size_t)(f / samples_per_bucket) * npixels;
+    const uint32_t localFrameIdx = f / gmon_buckets;
+    if (localFrameIdx > 0) {
+      const vec4 a = acc[p];
+      L = L + v3(a.x, a.y, a.z) * (float)localFrameIdx;
+      L = L / (float)(localFrameIdx + 1);
+    }
+    acc[p] = vec4{L.x, L.y, L.z, 1.0f};
+  }
+}
+
+// shaders/gmon.metal:14-55: per pixel, sort the bucket means by luma (stable bubble sort), Gini coefficient of the
+// sorted lumas, drop c = int(min(G, cap) * (n / 2)) values from both ends, average the rest.
+__global__ void __launch_bounds__(kBlock) k_gmon(vec4* __restrict__ acc, const vec4* __restrict__ buckets, uint32_t npixels,
+                                                  uint32_t nBuckets, float cap) {
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= npixels) return;
+  const vec3 lw = v3(0.2126f, 0.7152f, 0.0722f);  // gmon.metal:10
+  vec3 values[32];                                // maxBuckets (gmon.metal:12)
+  for (uint32_t i = 0; i < nBuckets; i++) {
+    const vec4 b = buckets[(size_t)i * npixels + p];
+    values[i] = v3(b.x, b.y, b.z);
+  }
+  for (uint32_t i = nBuckets; i > 1; i--)
+    for (uint32_t j = 1; j < i; j++)
+      if (dot(values[j], lw) < dot(values[j - 1], lw)) {
+        const vec3 temp = values[j - 1];
+        values[j - 1] = values[j];
+        values[j] = temp;
+      }
+  vec3 sum = v3(0.0f), weightedSum = v3(0.0f);
+  for (uint32_t i = 0; i < nBuckets; i++) {
+    sum = sum + values[i];
+    weightedSum = weightedSum + (float)(i + 1) * values[i];
+  }
+  float G = (2.0f * dot(weightedSum, lw)) / ((float)nBuckets * dot(sum, lw)) - (float)(nBuckets + 1) / (float)nBuckets;
+  G = fminf(G, cap);
+  // int(G * float(n / 2)); a NaN/negative G (all-black pixel with cap <= 0) keeps every bucket
+  const float cf = G * (float)(nBuckets / 2);
+  const int c = cf > 0.0f ? (int)cf : 0;
+  sum = v3(0.0f);
+  for (int i = c; i < (int)nBuckets - c; i++) sum = sum + values[i];
+  const vec3 color = sum / (float)((int)nBuckets - 2 * c);
+  acc[p] = vec4{color.x, color.y, color.z, 1.0f};
+}
+
 // ---- bookkeeping --------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_fold_counters(const BatchCounters* __restrict__ ctr, Totals* __restrict__ tot,
                                                            Segments seg, uint32_t counted) {
@@ -508,6 +572,14 @@ void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npix
                        uint32_t nonfinite_policy, BatchCounters* ctr) {
   hipLaunchKernelGGL(k_accumulate, dim3((npixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, acc, Lbuf, npixels, nsamples, n0,
                      nonfinite_policy, ctr);
+}
+void launch_accumulate_gmon(hipStream_t s, vec4* buckets, const vec4* Lbuf, uint32_t npixels, uint32_t nsamples, uint32_t n0,
+                            uint32_t samples_per_bucket, uint32_t gmon_buckets, uint32_t nonfinite_policy, BatchCounters* ctr) {
+  hipLaunchKernelGGL(k_accumulate_gmon, dim3((npixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, buckets, Lbuf, npixels, nsamples, n0,
+                     samples_per_bucket, gmon_buckets, nonfinite_policy, ctr);
+}
+void launch_gmon(hipStream_t s, vec4* acc, const vec4* buckets, uint32_t npixels, uint32_t nBuckets, float cap) {
+  hipLaunchKernelGGL(k_gmon, dim3((npixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, acc, buckets, npixels, nBuckets, cap);
 }
 void launch_fold_counters(hipStream_t s, const BatchCounters* ctr, Totals* tot, Segments seg, bool counted) {
   hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(kBlock), 0, s, ctr, tot, seg, counted ? 1u : 0u);

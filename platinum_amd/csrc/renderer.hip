@@ -107,6 +107,8 @@ struct pt_renderer {
   DevBuf<uint32_t> st_pid[2], spill, seg_active[2], seg_shadow;
   DevBuf<WaveStats> wave_stats;
   DevBuf<uint32_t> chunk_table[2];
+  DevBuf<vec4> gmon_buckets_d;  // [bucket][pixel] with PT_FLAG_GMON (renderer_pt.cpp:824-830)
+  float gmon_cap = 1.0f;        // GmonOptions.cap (pt_shader_defs.hpp:164-166)
   uint32_t nwaves = 0, seg_cap = 0, blocks_per_cu = 6, tile_contiguous = 0, refill_threshold = 48;
   DevBuf<BatchCounters> ctr;
   DevBuf<Totals> totals;
@@ -136,7 +138,7 @@ struct pt_renderer {
     if (bvh.tris) (void)hipFree(bvh.tris);
     bvh = LbvhResult{};
     for (int k = 0; k < 2; k++) { st_rayO[k].release(); st_rayD[k].release(); st_att[k].release(); st_pid[k].release(); }
-    seg_active[0].release(); seg_active[1].release(); seg_shadow.release(); wave_stats.release(); chunk_table[0].release(); chunk_table[1].release();
+    seg_active[0].release(); seg_active[1].release(); seg_shadow.release(); wave_stats.release(); chunk_table[0].release(); chunk_table[1].release(); gmon_buckets_d.release();
     hit.release(); sq_o.release(); sq_d.release(); sq_c.release(); Lbuf.release(); acc_own.release(); spill.release();
     acc = nullptr;
     started = false;
@@ -201,7 +203,17 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
   }
   if (mode == BATCH_RENDER) {
     ScopedTimer t(r, K_ACCUM);
-    launch_accumulate(s, r->acc, r->Lbuf.p, S.width * S.height, ns, n0, r->params.nonfinite_policy, ctr);
+    const uint32_t npix = S.width * S.height;
+    if (r->params.flags & PT_FLAG_GMON) {
+      const uint32_t buckets = r->params.gmon_buckets;
+      const uint32_t spb = (r->params.spp + buckets - 1) / buckets;  // renderer_pt.cpp:124-125
+      launch_accumulate_gmon(s, r->gmon_buckets_d.p, r->Lbuf.p, npix, ns, n0, spb, buckets, r->params.nonfinite_policy, ctr);
+      // the reference resolves after every frame with fullBuckets = gmonIdx + 1 (renderer_pt.cpp:164-179); only the last
+      // resolve of a batch is observable
+      launch_gmon(s, r->acc, r->gmon_buckets_d.p, npix, (n0 + ns - 1) / spb + 1, r->gmon_cap);
+    } else {
+      launch_accumulate(s, r->acc, r->Lbuf.p, npix, ns, n0, r->params.nonfinite_policy, ctr);
+    }
   }
   // BATCH_DEBUG still folds (to clear the per-wave statistics) but into a scratch Totals slot
   launch_fold_counters(s, ctr, mode == BATCH_DEBUG ? r->totals.p + 1 : r->totals.p, seg, count);
@@ -337,7 +349,8 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
   if ((uint64_t)p->width * p->height > (1ull << 28)) return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: image too large");
   if (p->integrator != PT_INTEGRATOR_SIMPLE && p->integrator != PT_INTEGRATOR_MIS) return fail(PT_ERR_INVALID_ARGUMENT, "bad integrator");
   if (p->nonfinite_policy > PT_NONFINITE_ZERO) return fail(PT_ERR_INVALID_ARGUMENT, "bad nonfinite_policy");
-  if (p->flags & PT_FLAG_GMON) return fail(PT_ERR_UNSUPPORTED, "GMoN (SURVEY §8f N1) is not part of this ABI version");
+  if ((p->flags & PT_FLAG_GMON) && (p->gmon_buckets < 1 || p->gmon_buckets > 32))
+    return fail(PT_ERR_INVALID_ARGUMENT, "gmon_buckets must be 1..32 (gmon.metal:12 maxBuckets)");
   if (scene->instance_count && (!scene->instances || !scene->instance_materials || !scene->meshes))
     return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: null scene arrays");
   PT_HIP(hipSetDevice(r->device));
@@ -456,6 +469,10 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
     PT_HIP(r->acc_own.alloc(npix));
     r->acc = r->acc_own.p;
   }
+  if (p->flags & PT_FLAG_GMON) {
+    PT_HIP(r->gmon_buckets_d.alloc((size_t)npix * p->gmon_buckets));
+    PT_HIP(hipMemsetAsync(r->gmon_buckets_d.p, 0, sizeof(vec4) * npix * p->gmon_buckets, r->stream));
+  }
   PT_HIP(hipMemsetAsync(r->acc, 0, sizeof(vec4) * npix, r->stream));
   PT_HIP(hipMemsetAsync(r->totals.p, 0, sizeof(Totals), r->stream));
   PT_HIP(hipStreamSynchronize(r->stream));
@@ -519,6 +536,22 @@ int pt_read_accumulator(pt_renderer* r, float* rgba_out) {
   int rc = pt_wait(r);
   if (rc != PT_OK) return rc;
   PT_HIP(hipMemcpy(rgba_out, r->acc, sizeof(vec4) * (size_t)r->S.width * r->S.height, hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+int pt_set_gmon_options(pt_renderer* r, const pt_gmon_options* o) {
+  if (!r || !o) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  r->gmon_cap = o->cap;
+  return PT_OK;
+}
+
+int pt_read_gmon_bucket(pt_renderer* r, uint32_t bucket, float* rgba_out) {
+  if (!r || !rgba_out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!r->started || !(r->params.flags & PT_FLAG_GMON) || bucket >= r->params.gmon_buckets) return fail(PT_ERR_BAD_STATE, "no such GMoN bucket");
+  int rc = pt_wait(r);
+  if (rc != PT_OK) return rc;
+  const size_t npix = (size_t)r->S.width * r->S.height;
+  PT_HIP(hipMemcpy(rgba_out, r->gmon_buckets_d.p + npix * bucket, sizeof(vec4) * npix, hipMemcpyDeviceToHost));
   return PT_OK;
 }
 

@@ -99,6 +99,17 @@ class Renderer:
         abi.check(self._lib, self._lib.pt_read_accumulator(self._h, out.ctypes.data))
         return out
 
+    def setGmonOptions(self, cap=1.0):
+        """gmonOptions().cap (renderer_pt.hpp:71)."""
+        o = abi.GmonOptions(cap)
+        abi.check(self._lib, self._lib.pt_set_gmon_options(self._h, C.byref(o)))
+
+    def readGmonBucket(self, bucket):
+        w, h = self.size
+        out = np.empty((h, w, 4), dtype=np.float32)
+        abi.check(self._lib, self._lib.pt_read_gmon_bucket(self._h, bucket, out.ctypes.data))
+        return out
+
     def accumulatorDevicePtr(self):
         return self._lib.pt_accumulator_device_ptr(self._h)
 

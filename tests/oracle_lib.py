@@ -46,6 +46,7 @@ def lib():
     L.orc_get_constants.argtypes = [C.c_void_p, C.POINTER(abi.Constants)]
     L.orc_get_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int]
+    L.orc_gmon_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]
     L.orc_trace_primary.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     L.orc_debug_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
     L.orc_get_stats.argtypes = [C.c_void_p, C.POINTER(OrcStats)]
@@ -119,6 +120,21 @@ class OracleScene:
         threads = threads or os.cpu_count() or 1
         self.L.orc_render(self.h, first_sample, nsamples, acc.ctypes.data, acc_n0, threads, int(count_traversal))
         return acc
+
+    def render_gmon(self, nsamples, threads=None):
+        """All `nsamples` (= params.spp) samples into the GMoN buckets; returns (buckets[B,H,W,4], resolved[H,W,4])."""
+        B = self.params.gmon_buckets
+        buckets = np.zeros((B, self.H, self.W, 4), dtype=np.float32)
+        self.L.orc_render(self.h, 0, nsamples, buckets.ctypes.data, 0, threads or os.cpu_count() or 1, 0)
+        spb = (self.params.spp + B - 1) // B
+        full = (nsamples - 1) // spb + 1
+        return buckets, self.gmon_resolve(buckets, full)
+
+    def gmon_resolve(self, buckets, full_buckets, cap=1.0):
+        out = np.zeros((self.H, self.W, 4), dtype=np.float32)
+        b = np.ascontiguousarray(buckets, dtype=np.float32)
+        self.L.orc_gmon_resolve(self.h, b.ctypes.data, full_buckets, cap, out.ctypes.data)
+        return out
 
     def trace_primary(self, sample_idx=0):
         out = np.zeros(self.W * self.H, dtype=[("t", "f4"), ("u", "f4"), ("v", "f4"), ("instance", "i4"), ("primitive", "i4")])

@@ -164,3 +164,27 @@ def test_odd_image_size_and_many_batches(gpu_renderer):
     acc = gpu_renderer.readbackAccumulator()
     ref = oracle_lib.OracleScene(sc, p).render(0, spp)
     assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("spp,buckets,sif", [(30, 15, 8), (17, 5, 3)])
+def test_gmon_matches_oracle(gpu_renderer, spp, buckets, sif):
+    """bucketed accumulation + Gini-weighted median of means, bit-identical to the oracle."""
+    sc = _scene("cornell_sphere")
+    w, h, bounces = 96, 64, 5
+    flags = abi.FLAG_MULTISCATTER_GGX | abi.FLAG_GMON
+    gpu_renderer.selectKernel(abi.INTEGRATOR_MIS)
+    gpu_renderer.startRender(sc, (w, h), spp, gmonBuckets=buckets, flags=flags, max_bounces=bounces, samples_in_flight=sif)
+    assert gpu_renderer.constants().gmonBuckets == buckets
+    gpu_renderer.render(0)
+    acc = gpu_renderer.readbackAccumulator()
+    o = oracle_lib.OracleScene(sc, make_params(w, h, spp, bounces, flags=flags, gmon_buckets=buckets))
+    ob, oresolved = o.render_gmon(spp)
+    for b in range(buckets):
+        assert gpu_renderer.readGmonBucket(b).tobytes() == ob[b].tobytes(), b
+    assert np.array_equal(acc.view(np.uint32), oresolved.view(np.uint32))
+    gpu_renderer.setGmonOptions(cap=0.25)
+    gpu_renderer.startRender(sc, (w, h), spp, gmonBuckets=buckets, flags=flags, max_bounces=bounces, samples_in_flight=sif)
+    gpu_renderer.render(0)
+    spb = (spp + buckets - 1) // buckets
+    assert np.array_equal(gpu_renderer.readbackAccumulator().view(np.uint32), o.gmon_resolve(ob, (spp - 1) // spb + 1, cap=0.25).view(np.uint32))
+    gpu_renderer.setGmonOptions(cap=1.0)

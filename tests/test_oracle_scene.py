@@ -69,3 +69,39 @@ def test_constants_cornell_default_camera():
     du = np.array([c.camera.pixelDeltaU.x, c.camera.pixelDeltaU.y, c.camera.pixelDeltaU.z])
     vh = 1.0 * (36.0 / 1.5) / 28.0
     assert np.linalg.norm(du) * 640 == pytest.approx(vh * 640 / 480, rel=1e-5)
+
+
+def test_gmon_resolve_properties():
+    """gmon.metal: identical buckets -> that value (G = 0); one outlier bucket is trimmed when the Gini coefficient is high."""
+    o = oracle_lib.OracleScene(scenes.cornell_scene(), make_params(4, 2, 15, 4, flags=abi.FLAG_MULTISCATTER_GGX | abi.FLAG_GMON, gmon_buckets=15))
+    b = np.zeros((15, 2, 4, 4), np.float32)
+    b[..., :3] = 0.25
+    b[..., 3] = 1
+    out = o.gmon_resolve(b, 15)
+    np.testing.assert_allclose(out[..., :3], 0.25, rtol=1e-6)
+    b2 = b.copy()
+    b2[7, 0, 0, :3] = 1000.0                      # a firefly in one bucket of one pixel
+    out2 = o.gmon_resolve(b2, 15)
+    assert out2[0, 0, 0] < 0.3                   # trimmed away (plain mean would be ~66.9)
+    assert abs(out2[1, 3, 0] - 0.25) < 1e-6
+    # cap = 0 -> plain mean of the buckets
+    out3 = o.gmon_resolve(b2, 15, cap=0.0)
+    assert out3[0, 0, 0] == pytest.approx((14 * 0.25 + 1000.0) / 15, rel=1e-5)
+
+
+def test_gmon_bucket_assignment_quirk():
+    """With GMoN the running-mean weight is frameIdx / gmonBuckets (kernel.metal:675), not the index inside the bucket:
+    with spp = 8, 4 buckets (2 samples per bucket) every sample has weight index < 1 until frame 4, so buckets 0 and 1 end
+    up holding just their LAST sample. Reproduced, not fixed."""
+    sc = scenes.cornell_scene()
+    p = make_params(24, 16, 8, 3, flags=abi.FLAG_MULTISCATTER_GGX | abi.FLAG_GMON, gmon_buckets=4)
+    o = oracle_lib.OracleScene(sc, p)
+    buckets, resolved = o.render_gmon(8)
+    singles = [oracle_lib.OracleScene(sc, make_params(24, 16, 8, 3)).debug_sample(s)[0] for s in range(8)]
+    assert buckets[0].tobytes() == singles[1].tobytes()        # frame 1 overwrote frame 0 (n = 1 // 4 = 0)
+    assert buckets[1].tobytes() == singles[3].tobytes()
+    # frames 4, 5 -> bucket 2 with n = 1 both times: ((L5 + ((L4 + 0 * 1) / 2) * 1) / 2): the first sample is halved twice
+    f32 = np.float32
+    b2 = ((singles[5][..., :3] + ((singles[4][..., :3] + f32(0)) / f32(2)) * f32(1)) / f32(2)).astype(np.float32)
+    assert buckets[2][..., :3].tobytes() == b2.tobytes()
+    assert resolved.shape == (16, 24, 4) and (resolved[..., 3] == 1).all()
