@@ -244,6 +244,45 @@ int pt_set_gmon_options(pt_renderer* r, const pt_gmon_options* options);
 /* One bucket image (W*H*4 floats), for parity checks. */
 int pt_read_gmon_bucket(pt_renderer* r, uint32_t bucket, float* rgba_out);
 
+/* ---- post-process chain + tonemap -> RGBA8 ---------------------------------------------------------
+ * Renderer::postProcessOptions() / tonemapOptions() / outputColorspace() (renderer_pt.hpp:65-73) edit option structs the
+ * UI writes every frame (core/postprocessing.hpp:168-218); pass order exposure, chromaticAberration, contrastSaturation,
+ * toneCurve, vignette, tonemap (renderer_pt.cpp:343-353).  Field names follow the reference's structs. */
+typedef struct pt_post_options {
+  float exposure;                                          /* ExposureOptions */
+  float ca_amount, ca_green_shift;                         /* ChromaticAberrationOptions (0, 70) */
+  float contrast, saturation;                              /* ContrastSaturationOptions */
+  float blacks, shadows, highlights, whites;               /* ToneCurveOptions */
+  float vig_amount, vig_midpoint, vig_feather, vig_power, vig_roundness; /* VignetteOptions (0, 0, 50, 20, 100) */
+} pt_post_options;
+
+enum { PT_TONEMAP_NONE = 0, PT_TONEMAP_AGX = 1, PT_TONEMAP_KHRONOS_PBR = 2, PT_TONEMAP_FLIM = 3 }; /* postprocess::Tonemapper */
+
+typedef struct pt_tonemap_options {
+  uint32_t tonemapper;                                     /* default AgX (postprocessing.hpp:219) */
+  float agx_offset[3], agx_slope[3], agx_power[3], agx_saturation;      /* agx::Look (looks::none) */
+  float khr_compression_start, khr_desaturation;           /* khronos_pbr::Options (0.8, 0.15) */
+  float flim_pre_exposure, flim_pre_formation_filter[3], flim_pre_formation_filter_strength; /* flim::Options */
+  float flim_extended_gamut_scale[3], flim_extended_gamut_rotation[3], flim_extended_gamut_mul[3];
+  float flim_sigmoid_log2_min, flim_sigmoid_log2_max, flim_sigmoid_toe[2], flim_sigmoid_shoulder[2];
+  float flim_negative_exposure, flim_negative_density, flim_print_backlight[3], flim_print_exposure, flim_print_density;
+  float flim_black_point;
+  uint32_t flim_auto_black_point;
+  float flim_post_formation_filter[3], flim_post_formation_filter_strength, flim_midtone_saturation;
+  float shadow_color[3], midtone_color[3], highlight_color[3];          /* LiftGammaGain (0.5 each) */
+  float shadow_offset, midtone_offset, highlight_offset;
+  pt_colorspace output_space;                              /* outputColorspace(), default Display P3 (renderer_pt.hpp:182) */
+} pt_tonemap_options;
+
+/* Fill with the reference's defaults (postprocessing.hpp:168-226, flim::presets::flim). */
+void pt_default_post_options(pt_post_options* o);
+void pt_default_tonemap_options(pt_tonemap_options* o);
+int pt_set_post_options(pt_renderer* r, const pt_post_options* o);
+int pt_set_tonemap_options(pt_renderer* r, const pt_tonemap_options* o);
+/* readbackRenderTarget() (renderer_pt.hpp:57, renderer_pt.cpp:1039-1059): the post-processed, tonemapped RGBA8 image
+ * (W*H*4 bytes, row-major, top-left origin). Blocks. */
+int pt_read_render_target(pt_renderer* r, uint8_t* rgba8_out);
+
 /* The float accumulator: W*H RGBA32F, row-major, top-left origin, running mean, alpha 1
  * (renderer_pt.cpp:812-821, kernel.metal:672-684).  Blocks like readbackRenderTarget (:1039-1059). */
 int pt_read_accumulator(pt_renderer* r, float* rgba_out);

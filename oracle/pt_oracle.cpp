@@ -838,6 +838,17 @@ M3d colorspace_toXYZ(const float r[2], const float g[2], const float b[2], const
 const float BT709_r[2] = {0.640f, 0.330f}, BT709_g[2] = {0.300f, 0.600f}, BT709_b[2] = {0.150f, 0.060f},
             D65[2] = {0.3127f, 0.3290f};  // core/colorspace.cpp:5, colorspace.hpp:47
 
+Mat3 compute_transform(const pt_colorspace& a, const pt_colorspace& b) {  // colorspace.hpp:61-63: dst.fromXYZ * src.toXYZ
+  M3d src = colorspace_toXYZ(a.r, a.g, a.b, a.w);
+  M3d dst = colorspace_toXYZ(b.r, b.g, b.b, b.w);
+  M3d t = m3_mul(m3_inv(dst), src);
+  Mat3 o;
+  o.c0 = f3((float)t.m[0][0], (float)t.m[0][1], (float)t.m[0][2]);
+  o.c1 = f3((float)t.m[1][0], (float)t.m[1][1], (float)t.m[1][2]);
+  o.c2 = f3((float)t.m[2][0], (float)t.m[2][1], (float)t.m[2][2]);
+  return o;
+}
+
 Mat3 compute_idt(const pt_colorspace& ws) {
   M3d src = colorspace_toXYZ(BT709_r, BT709_g, BT709_b, D65);
   M3d dst = colorspace_toXYZ(ws.r, ws.g, ws.b, ws.w);
@@ -1156,6 +1167,8 @@ float3 trace_path(const orc_scene& sc, uint32_t px, uint32_t py, uint32_t frameI
   return L;
 }
 
+#include "post_oracle.inc"
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1322,6 +1335,21 @@ int orc_gmon_resolve(const orc_scene* sc, const float* buckets, uint32_t nBucket
     float3 color = sum / (float)((int)nBuckets - 2 * c);
     out[4 * p] = color.x; out[4 * p + 1] = color.y; out[4 * p + 2] = color.z; out[4 * p + 3] = 1.0f;
   }
+  return 0;
+}
+
+// Post-process + tonemap the W*H*4 float image `acc` into RGBA8 (readbackRenderTarget, renderer_pt.cpp:1039-1059).
+int orc_postprocess(const orc_scene* sc, const float* acc, const pt_post_options* po, const pt_tonemap_options* to, uint8_t* rgba8_out,
+                    float* float_out /* optional W*H*3 pre-quantisation */) {
+  const uint32_t W = sc->params.width, H = sc->params.height;
+  const Mat3 odt = compute_transform(sc->params.working_space, to->output_space);
+  for (uint32_t y = 0; y < H; y++)
+    for (uint32_t x = 0; x < W; x++) {
+      float3 c = post::pixel(acc, W, H, x, y, *po, *to, odt);
+      uint32_t v = post::pack_rgba8(c);
+      memcpy(&rgba8_out[4 * ((size_t)y * W + x)], &v, 4);
+      if (float_out) { float* f = &float_out[3 * ((size_t)y * W + x)]; f[0] = c.x; f[1] = c.y; f[2] = c.z; }
+    }
   return 0;
 }
 

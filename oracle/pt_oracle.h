@@ -26,6 +26,8 @@ int orc_get_lights(const orc_scene* sc, pt_area_light* out, uint32_t capacity, u
 int orc_render(orc_scene* sc, uint32_t first_sample, uint32_t nsamples, float* acc, uint32_t acc_n0, int threads,
                int count_traversal);
 int orc_gmon_resolve(const orc_scene* sc, const float* buckets, uint32_t nBuckets, float cap, float* out);
+int orc_postprocess(const orc_scene* sc, const float* acc, const pt_post_options* po, const pt_tonemap_options* to, uint8_t* rgba8_out,
+                    float* float_out);
 int orc_trace_primary(orc_scene* sc, uint32_t sample_idx, pt_hit_record* out);
 int orc_debug_sample(orc_scene* sc, uint32_t sample_idx, float* radiance_out, int32_t* hits_out, int threads);
 int orc_debug_pixel(orc_scene* sc, uint32_t x, uint32_t y, uint32_t sample_idx, float* L_out);

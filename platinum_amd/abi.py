@@ -120,6 +120,31 @@ class GmonOptions(C.Structure):
     _fields_ = [("cap", C.c_float)]
 
 
+class PostOptions(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "exposure", "ca_amount", "ca_green_shift", "contrast", "saturation", "blacks", "shadows", "highlights", "whites",
+        "vig_amount", "vig_midpoint", "vig_feather", "vig_power", "vig_roundness")]
+
+
+class TonemapOptions(C.Structure):
+    _fields_ = [
+        ("tonemapper", C.c_uint32), ("agx_offset", C.c_float * 3), ("agx_slope", C.c_float * 3), ("agx_power", C.c_float * 3),
+        ("agx_saturation", C.c_float), ("khr_compression_start", C.c_float), ("khr_desaturation", C.c_float),
+        ("flim_pre_exposure", C.c_float), ("flim_pre_formation_filter", C.c_float * 3), ("flim_pre_formation_filter_strength", C.c_float),
+        ("flim_extended_gamut_scale", C.c_float * 3), ("flim_extended_gamut_rotation", C.c_float * 3), ("flim_extended_gamut_mul", C.c_float * 3),
+        ("flim_sigmoid_log2_min", C.c_float), ("flim_sigmoid_log2_max", C.c_float), ("flim_sigmoid_toe", C.c_float * 2),
+        ("flim_sigmoid_shoulder", C.c_float * 2), ("flim_negative_exposure", C.c_float), ("flim_negative_density", C.c_float),
+        ("flim_print_backlight", C.c_float * 3), ("flim_print_exposure", C.c_float), ("flim_print_density", C.c_float),
+        ("flim_black_point", C.c_float), ("flim_auto_black_point", C.c_uint32), ("flim_post_formation_filter", C.c_float * 3),
+        ("flim_post_formation_filter_strength", C.c_float), ("flim_midtone_saturation", C.c_float),
+        ("shadow_color", C.c_float * 3), ("midtone_color", C.c_float * 3), ("highlight_color", C.c_float * 3),
+        ("shadow_offset", C.c_float), ("midtone_offset", C.c_float), ("highlight_offset", C.c_float), ("output_space", Colorspace),
+    ]
+
+
+TONEMAP_NONE, TONEMAP_AGX, TONEMAP_KHRONOS_PBR, TONEMAP_FLIM = 0, 1, 2, 3
+
+
 class HitRecord(C.Structure):
     _fields_ = [("t", C.c_float), ("u", C.c_float), ("v", C.c_float), ("instance", C.c_int32), ("primitive", C.c_int32)]
 
@@ -153,6 +178,11 @@ SYMBOLS = [
     ("pt_read_accumulator", C.c_int, [C.c_void_p, C.c_void_p]),
     ("pt_accumulator_device_ptr", C.c_void_p, [C.c_void_p]),
     ("pt_set_gmon_options", C.c_int, [C.c_void_p, C.POINTER(GmonOptions)]),
+    ("pt_default_post_options", None, [C.POINTER(PostOptions)]),
+    ("pt_default_tonemap_options", None, [C.POINTER(TonemapOptions)]),
+    ("pt_set_post_options", C.c_int, [C.c_void_p, C.POINTER(PostOptions)]),
+    ("pt_set_tonemap_options", C.c_int, [C.c_void_p, C.POINTER(TonemapOptions)]),
+    ("pt_read_render_target", C.c_int, [C.c_void_p, C.c_void_p]),
     ("pt_read_gmon_bucket", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     ("pt_last_error", C.c_char_p, []),
     ("pt_get_constants", C.c_int, [C.c_void_p, C.POINTER(Constants)]),

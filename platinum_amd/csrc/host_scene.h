@@ -91,6 +91,17 @@ inline Mat3 compute_idt(const pt_colorspace& ws) {
   o.c2 = v3((float)t.m[2][0], (float)t.m[2][1], (float)t.m[2][2]);
   return o;
 }
+// color::transform(src, dst) for arbitrary colour spaces (the tonemap pass's odt = working -> output, renderer_pt.cpp:190)
+inline Mat3 compute_transform(const pt_colorspace& src_cs, const pt_colorspace& dst_cs) {
+  const M3d src = colorspace_to_xyz(src_cs.r, src_cs.g, src_cs.b, src_cs.w);
+  const M3d dst = colorspace_to_xyz(dst_cs.r, dst_cs.g, dst_cs.b, dst_cs.w);
+  const M3d t = m3_mul(m3_inv(dst), src);
+  Mat3 o;
+  o.c0 = v3((float)t.m[0][0], (float)t.m[0][1], (float)t.m[0][2]);
+  o.c1 = v3((float)t.m[1][0], (float)t.m[1][1], (float)t.m[1][2]);
+  o.c2 = v3((float)t.m[2][0], (float)t.m[2][1], (float)t.m[2][2]);
+  return o;
+}
 inline pt_float3 to_pt(vec3 v) { return {v.x, v.y, v.z, 0.0f}; }
 inline vec3 from_pt(const pt_float3& v) { return v3(v.x, v.y, v.z); }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "pt_device.h"
+#include "pt_post.h"
 
 namespace pt {
 
@@ -40,6 +41,7 @@ void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npix
 void launch_accumulate_gmon(hipStream_t s, vec4* buckets, const vec4* Lbuf, uint32_t npixels, uint32_t nsamples, uint32_t n0,
                             uint32_t samples_per_bucket, uint32_t gmon_buckets, uint32_t nonfinite_policy, BatchCounters* ctr);
 void launch_gmon(hipStream_t s, vec4* acc, const vec4* buckets, uint32_t npixels, uint32_t nBuckets, float cap);
+void launch_postprocess(hipStream_t s, const vec4* acc, uint32_t* rgba8, uint32_t W, uint32_t H, const PostConstants& pc);
 void launch_fold_counters(hipStream_t s, const BatchCounters* ctr, Totals* tot, Segments seg, bool counted);
 void launch_hit_records(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, const vec4* hit, Segments seg,
                         pt_hit_record* out);

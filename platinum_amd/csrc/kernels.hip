@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
+#include "pt_post.h"
 #include "pt_shade.h"
 
 namespace pt {
@@ -488,6 +489,15 @@ __global__ void __launch_bounds__(kBlock) k_gmon(vec4* __restrict__ acc, const v
   acc[p] = vec4{color.x, color.y, color.z, 1.0f};
 }
 
+// ---- post-process + tonemap -> RGBA8 (pt_post.h) ------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_postprocess(const vec4* __restrict__ acc, uint32_t* __restrict__ rgba8, uint32_t W,
+                                                         uint32_t H, PostConstants pc) {
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= W * H) return;
+  const uint32_t py = p / W, px = p - py * W;
+  rgba8[p] = pp_pack_rgba8(postprocess_pixel(acc, W, H, px, py, pc));
+}
+
 // ---- bookkeeping --------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_fold_counters(const BatchCounters* __restrict__ ctr, Totals* __restrict__ tot,
                                                            Segments seg, uint32_t counted) {
@@ -580,6 +590,9 @@ void launch_accumulate_gmon(hipStream_t s, vec4* buckets, const vec4* Lbuf, uint
 }
 void launch_gmon(hipStream_t s, vec4* acc, const vec4* buckets, uint32_t npixels, uint32_t nBuckets, float cap) {
   hipLaunchKernelGGL(k_gmon, dim3((npixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, acc, buckets, npixels, nBuckets, cap);
+}
+void launch_postprocess(hipStream_t s, const vec4* acc, uint32_t* rgba8, uint32_t W, uint32_t H, const PostConstants& pc) {
+  hipLaunchKernelGGL(k_postprocess, dim3((W * H + kBlock - 1) / kBlock), dim3(kBlock), 0, s, acc, rgba8, W, H, pc);
 }
 void launch_fold_counters(hipStream_t s, const BatchCounters* ctr, Totals* tot, Segments seg, bool counted) {
   hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(kBlock), 0, s, ctr, tot, seg, counted ? 1u : 0u);

@@ -109,6 +109,9 @@ struct pt_renderer {
   DevBuf<uint32_t> chunk_table[2];
   DevBuf<vec4> gmon_buckets_d;  // [bucket][pixel] with PT_FLAG_GMON (renderer_pt.cpp:824-830)
   float gmon_cap = 1.0f;        // GmonOptions.cap (pt_shader_defs.hpp:164-166)
+  pt_post_options post{};
+  pt_tonemap_options tonemap{};
+  DevBuf<uint32_t> render_target;  // RGBA8 (renderer_pt.cpp:832-835)
   uint32_t nwaves = 0, seg_cap = 0, blocks_per_cu = 6, tile_contiguous = 0, refill_threshold = 48;
   DevBuf<BatchCounters> ctr;
   DevBuf<Totals> totals;
@@ -138,7 +141,7 @@ struct pt_renderer {
     if (bvh.tris) (void)hipFree(bvh.tris);
     bvh = LbvhResult{};
     for (int k = 0; k < 2; k++) { st_rayO[k].release(); st_rayD[k].release(); st_att[k].release(); st_pid[k].release(); }
-    seg_active[0].release(); seg_active[1].release(); seg_shadow.release(); wave_stats.release(); chunk_table[0].release(); chunk_table[1].release(); gmon_buckets_d.release();
+    seg_active[0].release(); seg_active[1].release(); seg_shadow.release(); wave_stats.release(); chunk_table[0].release(); chunk_table[1].release(); gmon_buckets_d.release(); render_target.release();
     hit.release(); sq_o.release(); sq_d.release(); sq_c.release(); Lbuf.release(); acc_own.release(); spill.release();
     acc = nullptr;
     started = false;
@@ -295,6 +298,8 @@ int pt_create(const pt_create_info* info, pt_renderer** out) {
   if (info->device_ordinal < 0 || info->device_ordinal >= ndev) return fail(PT_ERR_INVALID_ARGUMENT, "pt_create: bad device ordinal");
   PT_HIP(hipSetDevice(info->device_ordinal));
   auto* r = new pt_renderer();
+  pt_default_post_options(&r->post);
+  pt_default_tonemap_options(&r->tonemap);
   r->device = info->device_ordinal;
   if (const char* e = getenv("PTAMD_REFILL")) r->refill_threshold = (uint32_t)atoi(e);
   if (const char* e = getenv("PTAMD_TILE_CONTIGUOUS")) r->tile_contiguous = (uint32_t)atoi(e);  // tuning knobs
@@ -536,6 +541,68 @@ int pt_read_accumulator(pt_renderer* r, float* rgba_out) {
   int rc = pt_wait(r);
   if (rc != PT_OK) return rc;
   PT_HIP(hipMemcpy(rgba_out, r->acc, sizeof(vec4) * (size_t)r->S.width * r->S.height, hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+void pt_default_post_options(pt_post_options* o) {  // core/postprocessing.hpp:168-198
+  if (!o) return;
+  memset(o, 0, sizeof(*o));
+  o->ca_green_shift = 70.0f;
+  o->vig_feather = 50.0f; o->vig_power = 20.0f; o->vig_roundness = 100.0f;
+}
+
+void pt_default_tonemap_options(pt_tonemap_options* o) {  // postprocessing.hpp:29-160, 209-226
+  if (!o) return;
+  memset(o, 0, sizeof(*o));
+  o->tonemapper = PT_TONEMAP_AGX;
+  for (int k = 0; k < 3; k++) { o->agx_slope[k] = 1.0f; o->agx_power[k] = 1.0f; }
+  o->agx_saturation = 1.0f;
+  o->khr_compression_start = 0.8f; o->khr_desaturation = 0.15f;
+  o->flim_pre_exposure = 4.3f;
+  for (int k = 0; k < 3; k++) { o->flim_pre_formation_filter[k] = 1.0f; o->flim_extended_gamut_mul[k] = 1.0f; o->flim_print_backlight[k] = 1.0f; o->flim_post_formation_filter[k] = 1.0f; }
+  o->flim_extended_gamut_scale[0] = 1.05f; o->flim_extended_gamut_scale[1] = 1.12f; o->flim_extended_gamut_scale[2] = 1.045f;
+  o->flim_extended_gamut_rotation[0] = 0.5f; o->flim_extended_gamut_rotation[1] = 2.0f; o->flim_extended_gamut_rotation[2] = 0.1f;
+  o->flim_sigmoid_log2_min = -10.0f; o->flim_sigmoid_log2_max = 22.0f;
+  o->flim_sigmoid_toe[0] = 0.440f; o->flim_sigmoid_toe[1] = 0.280f;
+  o->flim_sigmoid_shoulder[0] = 0.591f; o->flim_sigmoid_shoulder[1] = 0.779f;
+  o->flim_negative_exposure = 6.0f; o->flim_negative_density = 5.0f;
+  o->flim_print_exposure = 6.0f; o->flim_print_density = 27.5f;
+  o->flim_black_point = 0.0f; o->flim_auto_black_point = 1;
+  o->flim_midtone_saturation = 1.02f;
+  for (int k = 0; k < 3; k++) { o->shadow_color[k] = 0.5f; o->midtone_color[k] = 0.5f; o->highlight_color[k] = 0.5f; }
+  const float p3[4][2] = {{0.680f, 0.320f}, {0.265f, 0.690f}, {0.150f, 0.060f}, {0.3127f, 0.3290f}};  // colorspace.cpp:6
+  for (int k = 0; k < 2; k++) { o->output_space.r[k] = p3[0][k]; o->output_space.g[k] = p3[1][k]; o->output_space.b[k] = p3[2][k]; o->output_space.w[k] = p3[3][k]; }
+}
+
+int pt_set_post_options(pt_renderer* r, const pt_post_options* o) {
+  if (!r || !o) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  r->post = *o;
+  return PT_OK;
+}
+
+int pt_set_tonemap_options(pt_renderer* r, const pt_tonemap_options* o) {
+  if (!r || !o) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  if (o->tonemapper > PT_TONEMAP_FLIM) return fail(PT_ERR_INVALID_ARGUMENT, "bad tonemapper");
+  r->tonemap = *o;
+  return PT_OK;
+}
+
+int pt_read_render_target(pt_renderer* r, uint8_t* rgba8_out) {
+  if (!r || !rgba8_out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!r->started) return fail(PT_ERR_BAD_STATE, "pt_read_render_target before pt_start_render");
+  int rc = pt_wait(r);
+  if (rc != PT_OK) return rc;
+  const size_t npix = (size_t)r->S.width * r->S.height;
+  if (r->render_target.n != npix) PT_HIP(r->render_target.alloc(npix));
+  PostConstants pc;
+  pc.post = r->post;
+  pc.tm = r->tonemap;
+  const Mat3 odt = compute_transform(r->params.working_space, r->tonemap.output_space);  // renderer_pt.cpp:190-191
+  pc.odt = PPMat3{odt.c0, odt.c1, odt.c2};
+  launch_postprocess(r->stream, r->acc, r->render_target.p, r->S.width, r->S.height, pc);
+  PT_HIP(hipGetLastError());
+  PT_HIP(hipStreamSynchronize(r->stream));
+  PT_HIP(hipMemcpy(rgba8_out, r->render_target.p, npix * 4, hipMemcpyDeviceToHost));
   return PT_OK;
 }
 

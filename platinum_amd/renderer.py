@@ -99,6 +99,30 @@ class Renderer:
         abi.check(self._lib, self._lib.pt_read_accumulator(self._h, out.ctypes.data))
         return out
 
+    # renderer_pt.hpp:65-73: the option structs the UI edits every frame
+    def postProcessOptions(self):
+        o = abi.PostOptions()
+        self._lib.pt_default_post_options(C.byref(o))
+        return o
+
+    def tonemapOptions(self):
+        o = abi.TonemapOptions()
+        self._lib.pt_default_tonemap_options(C.byref(o))
+        return o
+
+    def setPostProcessOptions(self, o):
+        abi.check(self._lib, self._lib.pt_set_post_options(self._h, C.byref(o)))
+
+    def setTonemapOptions(self, o):
+        abi.check(self._lib, self._lib.pt_set_tonemap_options(self._h, C.byref(o)))
+
+    def readbackRenderTarget(self):
+        """readbackRenderTarget() (renderer_pt.cpp:1039-1059): (H, W, 4) uint8, post-processed + tonemapped."""
+        w, h = self.size
+        out = np.empty((h, w, 4), dtype=np.uint8)
+        abi.check(self._lib, self._lib.pt_read_render_target(self._h, out.ctypes.data))
+        return out
+
     def setGmonOptions(self, cap=1.0):
         """gmonOptions().cap (renderer_pt.hpp:71)."""
         o = abi.GmonOptions(cap)

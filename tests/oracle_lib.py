@@ -47,6 +47,7 @@ def lib():
     L.orc_get_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int]
     L.orc_gmon_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]
+    L.orc_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.PostOptions), C.POINTER(abi.TonemapOptions), C.c_void_p, C.c_void_p]
     L.orc_trace_primary.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     L.orc_debug_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
     L.orc_get_stats.argtypes = [C.c_void_p, C.POINTER(OrcStats)]
@@ -135,6 +136,13 @@ class OracleScene:
         b = np.ascontiguousarray(buckets, dtype=np.float32)
         self.L.orc_gmon_resolve(self.h, b.ctypes.data, full_buckets, cap, out.ctypes.data)
         return out
+
+    def postprocess(self, acc, post, tonemap, want_float=False):
+        acc = np.ascontiguousarray(acc, dtype=np.float32)
+        out = np.zeros((self.H, self.W, 4), dtype=np.uint8)
+        fl = np.zeros((self.H, self.W, 3), dtype=np.float32) if want_float else None
+        self.L.orc_postprocess(self.h, acc.ctypes.data, C.byref(post), C.byref(tonemap), out.ctypes.data, fl.ctypes.data if want_float else None)
+        return (out, fl) if want_float else out
 
     def trace_primary(self, sample_idx=0):
         out = np.zeros(self.W * self.H, dtype=[("t", "f4"), ("u", "f4"), ("v", "f4"), ("instance", "i4"), ("primitive", "i4")])

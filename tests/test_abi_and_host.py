@@ -53,7 +53,7 @@ int main(void) {
         subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), f, "-o", os.path.join(d, "t")])
         c_sizes = [int(v) for v in subprocess.check_output([os.path.join(d, "t")]).split()]
     # the ctypes mirror (platinum_amd/abi.py) must agree with the C compiler on every by-value struct
-    py_sizes = [C.sizeof(t) for t in (abi.RenderParams, abi.SceneSnapshot, abi.Stats, abi.CreateInfo, abi.HitRecord, abi.Camera, abi.Mesh)]
+    py_sizes = [C.sizeof(t) for t in (abi.RenderParams, abi.SceneSnapshot, abi.Stats, abi.CreateInfo, abi.HitRecord, abi.Camera, abi.Mesh, abi.PostOptions, abi.TonemapOptions)]
     assert c_sizes == py_sizes
 
 

@@ -188,3 +188,34 @@ def test_gmon_matches_oracle(gpu_renderer, spp, buckets, sif):
     spb = (spp + buckets - 1) // buckets
     assert np.array_equal(gpu_renderer.readbackAccumulator().view(np.uint32), o.gmon_resolve(ob, (spp - 1) // spb + 1, cap=0.25).view(np.uint32))
     gpu_renderer.setGmonOptions(cap=1.0)
+
+
+def test_postprocess_tonemap_rgba8_matches_oracle(gpu_renderer):
+    """exposure / CA / contrast-saturation / tone curve / vignette / tonemap / lift-gamma-gain / odt / sRGB
+    -> RGBA8, identical to the oracle for the three tonemappers (at most 1 LSB on a handful of pixels is tolerated in
+    case a future compiler changes one rounding; we currently see exact equality)."""
+    sc = _scene("cornell_sphere")
+    w, h = 160, 96
+    _start(gpu_renderer, sc, w, h, 4, 5)
+    gpu_renderer.render(0)
+    acc = gpu_renderer.readbackAccumulator()
+    o = oracle_lib.OracleScene(sc, make_params(w, h, 4, 5))
+    for tm in (abi.TONEMAP_AGX, abi.TONEMAP_KHRONOS_PBR, abi.TONEMAP_FLIM, abi.TONEMAP_NONE):
+        po, to = gpu_renderer.postProcessOptions(), gpu_renderer.tonemapOptions()
+        to.tonemapper = tm
+        if tm != abi.TONEMAP_AGX:                       # non-default grading on the other three
+            po.exposure, po.ca_amount, po.contrast, po.saturation = 0.7, 40.0, 12.0, -8.0
+            po.blacks, po.shadows, po.highlights, po.whites = 5.0, -10.0, 8.0, -4.0
+            po.vig_amount, po.vig_midpoint = -1.5, 10.0
+            to.shadow_color[0], to.highlight_color[2], to.midtone_offset = 0.55, 0.6, 4.0
+            to.agx_power[0] = 1.35
+        gpu_renderer.setPostProcessOptions(po)
+        gpu_renderer.setTonemapOptions(to)
+        g = gpu_renderer.readbackRenderTarget()
+        c = o.postprocess(acc, po, to)
+        diff = np.abs(g.astype(np.int16) - c.astype(np.int16))
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (tm, diff.max(), (diff > 0).mean())
+        assert np.array_equal(g, c), tm
+        assert g[..., :3].std() > 5
+    gpu_renderer.setPostProcessOptions(gpu_renderer.postProcessOptions())
+    gpu_renderer.setTonemapOptions(gpu_renderer.tonemapOptions())
