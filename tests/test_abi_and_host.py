@@ -42,7 +42,7 @@ SA(sizeof(pt_constants) == 176); SA(offsetof(pt_constants, totalLightPower) == 3
 SA(offsetof(pt_constants, idt) == 48); SA(offsetof(pt_constants, camera) == 96);
 #include <stdio.h>
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(pt_render_params), sizeof(pt_scene_snapshot), sizeof(pt_stats), sizeof(pt_create_info),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(pt_render_params), sizeof(pt_scene_snapshot), sizeof(pt_stats), sizeof(pt_create_info),
          sizeof(pt_hit_record), sizeof(pt_camera), sizeof(pt_mesh), sizeof(pt_post_options), sizeof(pt_tonemap_options));
   return 0;
 }
