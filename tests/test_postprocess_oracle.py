@@ -79,6 +79,7 @@ def test_agx_and_flim_are_monotonic_and_bounded(osc):
 def test_vignette_and_chromatic_aberration_are_spatial(osc):
     po, to = _defaults()
     to.tonemapper = abi.TONEMAP_NONE
+    to.output_space = scenes.colorspace(scenes.BT2020)   # odt = identity, so the channels stay separate
     acc = np.zeros((8, 16, 4), np.float32)
     acc[..., :3] = 0.5
     acc[..., 0] = np.linspace(0.1, 0.9, 16)[None, :]       # a horizontal ramp in red
