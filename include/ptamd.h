@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1u
+#define PT_ABI_VERSION 2u
 
 /* ---------------------------------------------------------------------------------------------------------- */
 /* Enums (same numeric values as the reference)                                                                 */
@@ -53,7 +53,7 @@ typedef enum pt_error {
   PT_ERR_HIP = -3,           /* a HIP runtime call failed; message has file:line and hipGetErrorString */
   PT_ERR_OUT_OF_MEMORY = -4,
   PT_ERR_BAD_STATE = -5,     /* e.g. pt_render_step before pt_start_render */
-  PT_ERR_UNSUPPORTED = -6,   /* a scene feature of a "next" row (textures, env map) */
+  PT_ERR_UNSUPPORTED = -6,   /* a scene feature that is not implemented */
   PT_ERR_BAD_LUT = -7
 } pt_error;
 
@@ -139,6 +139,25 @@ typedef struct pt_camera {
 /* core/colorspace.hpp:22-42: CIE xy chromaticities of the primaries and the white point */
 typedef struct pt_colorspace { float r[2], g[2], b[2], w[2]; } pt_colorspace;
 
+/* Scene textures. The reference uploads these pixel formats (loaders/texture.cpp:30-48) and samples
+ * them with address::repeat + filter::linear (bsdf.metal:24, kernel.metal:167, intersections.metal:33). */
+enum {
+  PT_TEX_RGBA8_SRGB = 0, /* MTL::PixelFormatRGBA8Unorm_sRGB: base colour / emission (decoded to linear before filtering) */
+  PT_TEX_RGBA8 = 1,      /* RGBA8Unorm: linear RGB (normal maps) */
+  PT_TEX_RG8 = 2,        /* RG8Unorm: roughness, metallic */
+  PT_TEX_R8 = 3,         /* R8Unorm: transmission / clearcoat */
+  PT_TEX_RGBA32F = 4     /* RGBA32Float: HDR environment maps */
+};
+typedef struct pt_texture {
+  const void* pixels;    /* row-major, top row first, tightly packed */
+  uint32_t width, height;
+  uint32_t format;       /* PT_TEX_* */
+  uint32_t _pad;
+} pt_texture;
+
+/* core/environment.hpp:15-19 AliasEntry, 12 B */
+typedef struct pt_alias_entry { float pdf, p; uint32_t aliasIdx; } pt_alias_entry;
+
 typedef struct pt_scene_snapshot {
   const pt_mesh* meshes;
   uint32_t mesh_count;
@@ -146,7 +165,11 @@ typedef struct pt_scene_snapshot {
   const pt_instance* instances;                    /* instance_count */
   const pt_instance_materials* instance_materials; /* instance_count */
   pt_camera camera;
-  /* textures / environment map: SURVEY §8f row N3, not part of this ABI version; texture ids must be -1 */
+  const pt_texture* textures;                      /* texture_count; MaterialGPU::*TextureId index this array */
+  uint32_t texture_count;
+  int32_t env_texture;                             /* Environment::textureId (scene envmap), -1 = none */
+  const pt_alias_entry* env_alias;                 /* width*height entries, or NULL: built by the library exactly as
+                                                      Environment::rebuildAliasTable (core/environment.cpp:5-91) */
 } pt_scene_snapshot;
 
 /* ---------------------------------------------------------------------------------------------------------- */
@@ -295,6 +318,8 @@ const char* pt_last_error(void);
 /* Parity / measurement surface (no reference counterpart; used by tests and bench.py)                          */
 
 int pt_get_constants(const pt_renderer* r, pt_constants* out);
+/* The environment alias table in use (given or built): copies up to `capacity` entries; *count = width*height or 0. */
+int pt_get_env_alias(const pt_renderer* r, pt_alias_entry* out, uint64_t capacity, uint64_t* count);
 /* Copies up to `capacity` lights; returns the light count in *count. */
 int pt_get_lights(const pt_renderer* r, pt_area_light* out, uint32_t capacity, uint32_t* count);
 

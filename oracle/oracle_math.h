@@ -51,6 +51,8 @@ static inline float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 static inline float mix(float a, float b, float t) { return a + (b - a) * t; }
 static inline float sign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 // Metal spec: reflect(I, N) = I - 2 * dot(N, I) * N
+static constexpr float PI_F = 3.14159265358979323846f;  // M_PI_F
+
 static inline float3 reflect(float3 I, float3 N) { return I - (2.0f * dot(N, I)) * N; }
 // Metal spec: refract(I, N, eta): k = 1 - eta^2 (1 - dot(N,I)^2); k < 0 ? 0 : eta*I - (eta*dot(N,I) + sqrt(k)) * N
 static inline float3 refract(float3 I, float3 N, float eta) {
@@ -60,7 +62,6 @@ static inline float3 refract(float3 I, float3 N, float eta) {
   return eta * I - (eta * d + sqrtf(k)) * N;
 }
 
-static constexpr float PI_F = 3.14159265358979323846f;  // M_PI_F
 
 // ---- deterministic transcendentals (contract shared, in prose, with the HIP kernels) ------------------------
 
@@ -88,6 +89,30 @@ static inline void sincos_det(float x, float* s_out, float* c_out) {
   *c_out = c;
 }
 static inline float cos_det(float x) { float s, c; sincos_det(x, &s, &c); return c; }
+
+// atan(x): cephes atanf range reduction (tan(3pi/8), tan(pi/8)) + degree-9 odd polynomial. No fma.
+static inline float atan_det(float xx) {
+  float x = fabsf(xx), y;
+  if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+  else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+  else y = 0.0f;
+  float z = x * x;
+  y = y + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x);
+  return xx < 0.0f ? -y : y;
+}
+// atan2(y, x) with the usual quadrant rules; atan2(0, 0) = 0.
+static inline float atan2_det(float y, float x) {
+  if (x > 0.0f) return atan_det(y / x);
+  if (x < 0.0f) return y >= 0.0f ? atan_det(y / x) + PI_F : atan_det(y / x) - PI_F;
+  if (y > 0.0f) return 1.5707963267948966f;
+  if (y < 0.0f) return -1.5707963267948966f;
+  return 0.0f;
+}
+// acos(x) = atan2(sqrt((1 - x) * (1 + x)), x), x clamped to [-1, 1]
+static inline float acos_det(float x) {
+  x = fminf(fmaxf(x, -1.0f), 1.0f);
+  return atan2_det(sqrtf((1.0f - x) * (1.0f + x)), x);
+}
 
 // log2(x), x > 0 finite normal: x = m * 2^e with m in [sqrt(1/2), sqrt(2)); cephes logf polynomial.
 static inline float log2_det(float x) {

@@ -215,6 +215,35 @@ inline float lut3(const Lut& l, float cx, float cy, float cz) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Scene textures.  Filtering contract (ours; Apple's texture unit is closed): sampler(address::repeat,
+// filter::linear) with normalised coordinates: x = u*W - 0.5, i0 = floor(x), w = x - i0, both taps wrapped modulo W,
+// lerp a + (b - a) * w along x then y.  Texels are decoded to linear float4 up front: UNORM8 = i / 255, sRGB8 through
+// the exact piecewise curve evaluated in double and rounded once (alpha stays linear), R8 -> (r,0,0,1), RG8 -> (r,g,0,1).
+// ------------------------------------------------------------------------------------------------------------
+struct Tex { int w = 0, h = 0; std::vector<float> px; };  // px: h*w*4
+
+inline int wrapi(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+
+float4 tex_sample(const Tex& t, float2 uv) {
+  const float fx = uv.x * (float)t.w - 0.5f, fy = uv.y * (float)t.h - 0.5f;
+  const float x0f = floorf(fx), y0f = floorf(fy);
+  const float wx = fx - x0f, wy = fy - y0f;
+  const int x0 = wrapi((int)x0f, t.w), x1 = wrapi((int)x0f + 1, t.w);
+  const int y0 = wrapi((int)y0f, t.h), y1 = wrapi((int)y0f + 1, t.h);
+  const float* p00 = &t.px[4 * ((size_t)y0 * t.w + x0)];
+  const float* p01 = &t.px[4 * ((size_t)y0 * t.w + x1)];
+  const float* p10 = &t.px[4 * ((size_t)y1 * t.w + x0)];
+  const float* p11 = &t.px[4 * ((size_t)y1 * t.w + x1)];
+  float o[4];
+  for (int c = 0; c < 4; c++) {
+    const float a = p00[c] + (p01[c] - p00[c]) * wx;
+    const float b = p10[c] + (p11[c] - p10[c]) * wx;
+    o[c] = a + (b - a) * wy;
+  }
+  return {o[0], o[1], o[2], o[3]};
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // bsdf.metal
 // ------------------------------------------------------------------------------------------------------------
 enum SampleFlags {  // defs.metal:264-272
@@ -225,16 +254,25 @@ enum SampleFlags {  // defs.metal:264-272
 struct Mat3 { float3 c0, c1, c2; };
 inline float3 mul(const Mat3& m, float3 v) { return (m.c0 * v.x + m.c1 * v.y) + m.c2 * v.z; }
 
-// defs.metal:283-299 + bsdf.metal:12-43 (texture fetches are a "next" row: ids must be -1)
+// defs.metal:283-299 + bsdf.metal:12-43
 struct ShadingContext {
   float3 albedo; float roughness, metallic, transmission, clearcoat, clearcoatRoughness, anisotropy, ior;
   int flags; float3 emission;
-  ShadingContext(const pt_material_gpu& mat, const Mat3& idt) {
+  ShadingContext(const pt_material_gpu& mat, float2 uv, const Mat3& idt, const std::vector<Tex>& textures) {
     albedo = f3(mat.baseColor[0], mat.baseColor[1], mat.baseColor[2]);
     emission = f3(mat.emission.x, mat.emission.y, mat.emission.z);
     roughness = mat.roughness; metallic = mat.metallic; transmission = mat.transmission;
     clearcoat = mat.clearcoat; clearcoatRoughness = mat.clearcoatRoughness; anisotropy = mat.anisotropy;
     ior = mat.ior; flags = mat.flags;
+    if (mat.baseTextureId >= 0) { float4 t = tex_sample(textures[mat.baseTextureId], uv); albedo = f3(t.x, t.y, t.z); }          // :25-26
+    if (mat.emissionTextureId >= 0) { float4 t = tex_sample(textures[mat.emissionTextureId], uv); emission *= f3(t.x, t.y, t.z); }  // :27-28
+    if (mat.transmissionTextureId >= 0) transmission = tex_sample(textures[mat.transmissionTextureId], uv).x;                     // :29-30
+    if (mat.clearcoatTextureId >= 0) clearcoat = tex_sample(textures[mat.clearcoatTextureId], uv).x;                              // :31-32
+    if (mat.rmTextureId >= 0) {                                                                                                    // :33-37
+      float4 rm = tex_sample(textures[mat.rmTextureId], uv);
+      roughness *= rm.x;
+      metallic *= rm.y;
+    }
     albedo = mul(idt, albedo);      // :40
     emission = mul(idt, emission);  // :41
     emission *= mat.emissionStrength;  // :42
@@ -652,6 +690,10 @@ struct orc_scene {
   std::vector<pt_instance> instances;
   std::vector<Xform> xforms;
   std::vector<std::vector<pt_material_gpu>> inst_materials;
+  std::vector<uint8_t> inst_nonopaque;  // MTL::AccelerationStructureInstanceOptionNonOpaque (renderer_pt.cpp:714-729)
+  std::vector<Tex> textures;
+  int env_texture = -1;
+  std::vector<pt_alias_entry> env_alias;
   std::vector<WorldTri> tris;       // instance-major: global id order == (instance, primitive) order
   std::vector<uint32_t> bvh_order;  // permutation of triangle ids used by leaves
   std::vector<BvhNode> bvh;
@@ -744,8 +786,23 @@ inline bool slab(const BvhNode& n, const Ray& r, const float inv[3], float tbest
   return tn <= tf * 1.0000005f + 1e-30f;
 }
 
+// intersections.metal:8-39 alphaTestIntersectionFunction: called for every candidate on a non-opaque instance
+bool alpha_test(const orc_scene& sc, uint32_t inst, uint32_t prim, float u, float v, float r) {
+  const MeshData& mesh = sc.meshes[sc.instances[inst].accelerationStructureIndex];
+  const pt_material_gpu& material = sc.inst_materials[inst][mesh.slots[prim]];
+  float alpha = material.baseColor[3];
+  if (material.baseTextureId >= 0) {
+    const uint32_t* idx = &mesh.indices[3 * (size_t)prim];
+    float2 tc[3];
+    for (int i = 0; i < 3; i++) tc[i] = {mesh.vdata[idx[i]].texCoords[0], mesh.vdata[idx[i]].texCoords[1]};
+    float2 surfaceUV = interpolate(tc, {u, v});
+    alpha *= tex_sample(sc.textures[material.baseTextureId], surfaceUV).w;
+  }
+  return alpha > r;
+}
+
 template <bool ANY>
-Intersection intersect_scene(const orc_scene& sc, const Ray& ray, TraversalCounters* tc) {
+Intersection intersect_scene(const orc_scene& sc, const Ray& ray, float payload_r, TraversalCounters* tc) {
   Intersection best;
   float tbest = ray.max_distance;
   uint32_t best_id = 0xffffffffu;
@@ -753,6 +810,7 @@ Intersection intersect_scene(const orc_scene& sc, const Ray& ray, TraversalCount
     float t, u, v;
     if (tc) tc->tris++;
     if (!intersect_triangle(ray, sc.tris[id], &t, &u, &v)) return false;
+    if (sc.inst_nonopaque[sc.tris[id].inst] && !alpha_test(sc, sc.tris[id].inst, sc.tris[id].prim, u, v, payload_r)) return false;
     if (ANY) { best.hit = true; return true; }
     if (!best.hit || t < tbest || (t == tbest && id < best_id)) {
       best.hit = true; tbest = t; best_id = id;
@@ -903,7 +961,74 @@ void update_constants(orc_scene& sc, const pt_camera& cam) {
 // core/material.hpp:44-47 isEmissive (textures are a "next" row)
 inline bool is_emissive(const pt_material_gpu& m) {
   float3 e = from_pt(m.emission) * m.emissionStrength;
-  return length_squared(e) > 0.0f;
+  return length_squared(e) > 0.0f || m.emissionTextureId >= 0;  // textures.contains(TextureSlot::Emission)
+}
+
+// Decode one snapshot texture to linear float4 (see the filtering contract above).
+Tex decode_texture(const pt_texture& t) {
+  Tex o;
+  o.w = (int)t.width; o.h = (int)t.height;
+  const size_t n = (size_t)t.width * t.height;
+  o.px.resize(4 * n);
+  static float srgb_lut[256];
+  static bool init = false;
+  if (!init) {
+    for (int i = 0; i < 256; i++) {
+      double c = i / 255.0;
+      srgb_lut[i] = (float)(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
+    }
+    init = true;
+  }
+  const uint8_t* b = (const uint8_t*)t.pixels;
+  const float* f = (const float*)t.pixels;
+  for (size_t i = 0; i < n; i++) {
+    float* d = &o.px[4 * i];
+    switch (t.format) {
+      case PT_TEX_RGBA8_SRGB: d[0] = srgb_lut[b[4 * i]]; d[1] = srgb_lut[b[4 * i + 1]]; d[2] = srgb_lut[b[4 * i + 2]]; d[3] = (float)b[4 * i + 3] / 255.0f; break;
+      case PT_TEX_RGBA8: for (int c = 0; c < 4; c++) d[c] = (float)b[4 * i + c] / 255.0f; break;
+      case PT_TEX_RG8: d[0] = (float)b[2 * i] / 255.0f; d[1] = (float)b[2 * i + 1] / 255.0f; d[2] = 0.0f; d[3] = 1.0f; break;
+      case PT_TEX_R8: d[0] = (float)b[i] / 255.0f; d[1] = 0.0f; d[2] = 0.0f; d[3] = 1.0f; break;
+      default: for (int c = 0; c < 4; c++) d[c] = f[4 * i + c]; break;  // PT_TEX_RGBA32F
+    }
+  }
+  return o;
+}
+
+// core/environment.cpp:5-91 Environment::rebuildAliasTable (Vose's method on luma-proportional importance)
+std::vector<pt_alias_entry> rebuild_alias_table(const Tex& texture) {
+  const uint64_t n = (uint64_t)texture.w * texture.h;
+  std::vector<pt_alias_entry> table(n, pt_alias_entry{0.0f, 0.0f, 0u});
+  float totalImportance = 0.0f;
+  std::vector<float> importance;
+  importance.reserve(n);
+  const float3 lumaCoeffs = f3(0.2126f, 0.7152f, 0.0722f);
+  for (uint64_t i = 0; i < n; i++) {
+    float luma = dot(f3(texture.px[4 * i], texture.px[4 * i + 1], texture.px[4 * i + 2]), lumaCoeffs);
+    importance.push_back(luma);
+    totalImportance += luma;
+  }
+  float scale = (float)n / totalImportance;
+  for (uint64_t i = 0; i < n; i++) {
+    importance[i] *= scale;
+    table[i].pdf = importance[i];
+  }
+  std::vector<size_t> small, large;
+  for (uint64_t i = 0; i < n; i++) {
+    if (importance[i] < 1.0f) small.push_back(i);
+    else large.push_back(i);
+  }
+  while (!small.empty() && !large.empty()) {
+    size_t l = small.back(); small.pop_back();
+    size_t g = large.back(); large.pop_back();
+    table[l].p = importance[l];
+    table[l].aliasIdx = (uint32_t)g;
+    importance[g] = (importance[g] + importance[l]) - 1.0f;
+    if (importance[g] < 1.0f) small.push_back(g);
+    else large.push_back(g);
+  }
+  while (!large.empty()) { size_t g = large.back(); large.pop_back(); table[g].p = 1.0f; }
+  while (!small.empty()) { size_t l = small.back(); small.pop_back(); table[l].p = 1.0f; }
+  return table;
 }
 
 // renderer_pt.cpp:838-917 rebuildLightData (area lights)
@@ -938,7 +1063,7 @@ void rebuild_light_data(orc_scene& sc) {
     }
   }
   sc.constants.lightCount = (uint32_t)sc.lights.size();
-  sc.constants.envLightCount = 0;
+  sc.constants.envLightCount = sc.env_texture >= 0 ? 1 : 0;
   sc.constants.totalLightPower = total;
 }
 
@@ -1008,7 +1133,12 @@ Hit getIntersectionData(const orc_scene& sc, const Ray& ray, const Intersection&
   float3 wsGeometricNormal = normalize(transformVec(geometricNormal, objectToWorld));
 
   Frame frame = Frame::fromNT(wsSurfaceNormal, wsSurfaceTangent, tangentSign);
-  // normal map (kernel.metal:166-175): textures are a "next" row, normalTextureId must be -1
+  if (material.normalTextureId >= 0) {  // kernel.metal:166-175
+    float4 t = tex_sample(sc.textures[material.normalTextureId], surfaceUV);
+    float3 sampledNormal = f3(t.x, t.y, t.z) * 2.0f - f3(1.0f);
+    wsSurfaceNormal = frame.localToWorld(sampledNormal);
+    frame = Frame::fromNormal(wsSurfaceNormal);
+  }
   float3 wo = frame.worldToLocal(-ray.direction);
   return {wsHitPoint, wsSurfaceNormal, wsGeometricNormal, surfaceUV, wo, frame, &material};
 }
@@ -1048,6 +1178,39 @@ LightSample sampleAreaLight(const orc_scene& sc, const Hit& hit, const pt_area_l
   return ls;
 }
 
+// kernel.metal:20-25 rayDirToUv, :27-34 uvToRayDir
+inline float2 rayDirToUv(float3 dir) {
+  float phi = atan2_det(-dir.z, -dir.x);
+  float theta = acos_det(dir.y);
+  return {phi / (2.0f * PI_F), theta / PI_F};
+}
+inline float3 uvToRayDir(float2 uv) {
+  float y, r, cosPhi, sinPhi;
+  sincos_det(uv.y * PI_F, &r, &y);
+  sincos_det(uv.x * 2.0f * PI_F, &sinPhi, &cosPhi);
+  return normalize(f3(-cosPhi * r, y, -sinPhi * r));
+}
+
+// kernel.metal:440-467 sampleEnvironmentLight
+LightSample sampleEnvironmentLight(const orc_scene& sc, float2 r) {
+  const Tex& texture = sc.textures[sc.env_texture];
+  uint64_t w = (uint64_t)texture.w, h = (uint64_t)texture.h;
+  uint64_t n = w * h;
+  uint64_t i = std::min<uint64_t>(n - 1, (uint64_t)(r.x * (float)n));
+  if (r.y >= sc.env_alias[i].p) i = sc.env_alias[i].aliasIdx;
+  uint64_t x = i % w, y = i / w;
+  float2 uv = {(float)x / (float)w, (float)y / (float)h};
+  float4 Le = tex_sample(texture, uv);
+  float3 wi = uvToRayDir(uv);
+  LightSample ls;
+  ls.Li = f3(Le.x, Le.y, Le.z);
+  ls.pos = wi * 100.0f;
+  ls.normal = -wi;
+  ls.wi = wi;
+  ls.pdf = sc.env_alias[i].pdf / (4.0f * PI_F);
+  return ls;
+}
+
 struct PathLog { int32_t* hits; uint32_t stride; uint32_t pixel; };  // hits[(bounce*stride + pixel)*2 + {0,1}]
 
 struct ThreadStats { uint64_t closest = 0, shadow = 0, shaded = 0, nonfinite = 0; TraversalCounters tc_closest, tc_shadow; bool verbose = false; };
@@ -1072,16 +1235,34 @@ float3 trace_path(const orc_scene& sc, uint32_t px, uint32_t py, uint32_t frameI
   TraversalCounters* tcs = count_traversal ? &st.tc_shadow : nullptr;
 
   for (uint32_t bounce = 0; bounce < sc.params.max_bounces; bounce++) {
-    float ir = halton.sample1d();  // alpha-test payload (kernel.metal:510); unused without alpha textures
-    (void)ir;
+    float ir = halton.sample1d();  // alpha-test payload (kernel.metal:510)
     st.closest++;
-    Intersection isect = intersect_scene<false>(sc, ray, tcc);
+    Intersection isect = intersect_scene<false>(sc, ray, ir, tcc);
     if (log) {
       int32_t* h = &log->hits[((size_t)bounce * log->stride + log->pixel) * 2];
       h[0] = isect.hit ? (int32_t)isect.instance_id : -1;
       h[1] = isect.hit ? (int32_t)isect.primitive_id : -1;
     }
-    if (!isect.hit) {  // kernel.metal:517-543 (no env lights in this ABI version)
+    if (!isect.hit) {  // kernel.metal:517-543 (simple integrator :299-311: no MIS weight)
+      if (sc.env_texture >= 0) {
+        const Tex& texture = sc.textures[sc.env_texture];
+        float2 uv = rayDirToUv(ray.direction);
+        float4 t = tex_sample(texture, uv);
+        const float3 Le = f3(t.x, t.y, t.z);
+        if (!mis || bounce == 0 || (lastSample.flags & Sample_Specular)) {
+          L += attenuation * Le;
+        } else {
+          // uint32_t x = w * uv.x (kernel.metal:530-531): uv.x is negative for half the sphere (atan2 range); the
+          // float->uint conversion of a negative value is defined here as 0, and indices are clamped into the table
+          uint32_t w = (uint32_t)texture.w, h = (uint32_t)texture.h;
+          float fxw = (float)w * uv.x, fyh = (float)h * uv.y;
+          uint32_t x = fxw > 0.0f ? (uint32_t)fxw : 0u, y = fyh > 0.0f ? (uint32_t)fyh : 0u;
+          x = std::min(x, w - 1); y = std::min(y, h - 1);
+          float lightPdf = sc.env_alias[(size_t)y * w + x].pdf * 0.25f * 0.318309886183790671538f;  // M_1_PI_F
+          float bsdfWeight = lastSample.pdf / (lastSample.pdf + lightPdf);
+          L += attenuation * bsdfWeight * Le;
+        }
+      }
       L += attenuation * backgroundColor;
       break;
     }
@@ -1094,7 +1275,7 @@ float3 trace_path(const orc_scene& sc, uint32_t px, uint32_t py, uint32_t frameI
     float4 r = {r01.x, r01.y, r2, r3};
     float2 rc = halton.sample2d();
 
-    ShadingContext ctx(*hit.material, sc.idt);
+    ShadingContext ctx(*hit.material, hit.uv, sc.idt, sc.textures);
     BSDF bsdf(ctx, C.flags, sc.luts);
     Sample sample = bsdf.sample(hit.wo, r, rc);
 
@@ -1114,14 +1295,23 @@ float3 trace_path(const orc_scene& sc, uint32_t px, uint32_t py, uint32_t frameI
     if (mis && (ctx.roughness > 0.0f || ctx.metallic + ctx.transmission < 1.0f)) {  // kernel.metal:587-639
       float2 rl = halton.sample2d();
       float rz = halton.sample1d();
-      // pInfinite (kernel.metal:593-596): envCount is 0 in this ABI version. With no lights at all the
-      // reference indexes envLights[0] out of bounds (UB); we skip NEE but keep the dimension schedule.
-      if (C.lightCount > 0) {
-        const float pInfinite = 0.0f;
-        rz = (rz - pInfinite) / (1.0f - pInfinite);
-        const pt_area_light& light = sampleLightPower(sc, rz);
-        float pLight = (1.0f - pInfinite) * light.power / C.totalLightPower;
-        LightSample lightSample = sampleAreaLight(sc, hit, light, rl);
+      // kernel.metal:590-616. With neither area lights nor an environment the reference indexes envLights[0] out of
+      // bounds (UB); we skip NEE then but keep the dimension schedule.
+      const uint32_t envCount = C.envLightCount;
+      if (C.lightCount > 0 || envCount > 0) {
+        const float pInfinite = C.lightCount == 0 ? 1.0f : (float)envCount / (float)(envCount + 1);
+        LightSample lightSample;
+        float pLight = 0;
+        if (rz < pInfinite) {
+          rz /= pInfinite;  // (selects among envCount lights; there is one)
+          pLight = pInfinite / (float)envCount;
+          lightSample = sampleEnvironmentLight(sc, rl);
+        } else {
+          rz = (rz - pInfinite) / (1.0f - pInfinite);
+          const pt_area_light& light = sampleLightPower(sc, rz);
+          pLight = (1.0f - pInfinite) * light.power / C.totalLightPower;
+          lightSample = sampleAreaLight(sc, hit, light, rl);
+        }
 
         const float3 wi = hit.frame.worldToLocal(lightSample.wi);
         const Eval bsdfEval = bsdf.eval(hit.wo, wi);
@@ -1132,9 +1322,8 @@ float3 trace_path(const orc_scene& sc, uint32_t px, uint32_t py, uint32_t frameI
           shadow.min_distance = 1e-3f;
           shadow.max_distance = length(lightSample.pos - hit.pos) - 1e-3f;
           float ir2 = halton.sample1d();
-          (void)ir2;
           st.shadow++;
-          bool occluded = intersect_scene<true>(sc, shadow, tcs).hit;
+          bool occluded = intersect_scene<true>(sc, shadow, ir2, tcs).hit;
           if (!occluded) {
             float pdfLight = pLight * lightSample.pdf;
             float3 Ld = lightSample.Li * bsdfEval.f * fabsf(wi.z) / (pdfLight + bsdfEval.pdf);
@@ -1208,8 +1397,16 @@ orc_scene* orc_scene_create(const pt_scene_snapshot* snap, const pt_render_param
     md.indices.assign(pm.indices, pm.indices + 3 * (size_t)pm.triangle_count);
     md.slots.assign(pm.material_slots, pm.material_slots + pm.triangle_count);
   }
+  for (uint32_t t = 0; t < snap->texture_count; t++) sc->textures.push_back(decode_texture(snap->textures[t]));
+  sc->env_texture = (snap->env_texture >= 0 && (uint32_t)snap->env_texture < snap->texture_count) ? snap->env_texture : -1;
+  if (sc->env_texture >= 0) {
+    const Tex& et = sc->textures[sc->env_texture];
+    if (snap->env_alias) sc->env_alias.assign(snap->env_alias, snap->env_alias + (size_t)et.w * et.h);
+    else sc->env_alias = rebuild_alias_table(et);
+  }
   sc->instances.assign(snap->instances, snap->instances + snap->instance_count);
   sc->xforms.resize(snap->instance_count);
+  sc->inst_nonopaque.assign(snap->instance_count, 0);
   sc->inst_materials.resize(snap->instance_count);
   for (uint32_t i = 0; i < snap->instance_count; i++) {
     const pt_instance& in = snap->instances[i];
@@ -1221,8 +1418,9 @@ orc_scene* orc_scene_create(const pt_scene_snapshot* snap, const pt_render_param
     sc->inst_materials[i].assign(im.materials, im.materials + im.material_count);
     // renderer_pt.cpp:626-633: the Renderer derives the Emissive / Anisotropic flags when it fills MaterialGPU
     for (auto& m : sc->inst_materials[i]) {
-      if (length_squared(from_pt(m.emission) * m.emissionStrength) > 0.0f) m.flags |= PT_MATERIAL_EMISSIVE;
+      if (is_emissive(m)) m.flags |= PT_MATERIAL_EMISSIVE;
       if (m.anisotropy != 0.0f) m.flags |= PT_MATERIAL_ANISOTROPIC;
+      if (m.flags & PT_MATERIAL_USE_ALPHA) sc->inst_nonopaque[i] = 1;  // renderer_pt.cpp:714-729
     }
     const MeshData& md = sc->meshes[in.accelerationStructureIndex];
     size_t ntri = md.indices.size() / 3;
@@ -1243,6 +1441,21 @@ orc_scene* orc_scene_create(const pt_scene_snapshot* snap, const pt_render_param
 void orc_scene_destroy(orc_scene* sc) { delete sc; }
 
 int orc_get_constants(const orc_scene* sc, pt_constants* out) { *out = sc->constants; return 0; }
+
+float orc_atan2(float y, float x) { return atan2_det(y, x); }
+float orc_acos(float x) { return acos_det(x); }
+void orc_tex_sample(const orc_scene* sc, int texture, float u, float v, float out[4]) {
+  float4 t = tex_sample(sc->textures[texture], float2{u, v});
+  out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+}
+void orc_ray_dir_to_uv(const float dir[3], float out[2]) { float2 uv = rayDirToUv(f3(dir[0], dir[1], dir[2])); out[0] = uv.x; out[1] = uv.y; }
+void orc_uv_to_ray_dir(const float uv[2], float out[3]) { float3 d = uvToRayDir(float2{uv[0], uv[1]}); out[0] = d.x; out[1] = d.y; out[2] = d.z; }
+
+int orc_get_env_alias(const orc_scene* sc, pt_alias_entry* out, uint64_t capacity, uint64_t* count) {
+  *count = sc->env_alias.size();
+  for (uint64_t i = 0; i < std::min<uint64_t>(capacity, *count); i++) out[i] = sc->env_alias[i];
+  return 0;
+}
 
 int orc_get_lights(const orc_scene* sc, pt_area_light* out, uint32_t capacity, uint32_t* count) {
   *count = (uint32_t)sc->lights.size();
@@ -1361,7 +1574,8 @@ int orc_trace_primary(orc_scene* sc, uint32_t sample_idx, pt_hit_record* out) {
       float2 a = halton.sample2d();
       float2 b = halton.sample2d();
       Ray ray = spawnRayFromCamera(sc->constants.camera, x, y, a, b);
-      Intersection is = intersect_scene<false>(*sc, ray, nullptr);
+      float ir = halton.sample1d();
+      Intersection is = intersect_scene<false>(*sc, ray, ir, nullptr);
       pt_hit_record& h = out[(size_t)y * W + x];
       h.t = is.hit ? is.distance : 0.0f; h.u = is.hit ? is.u : 0.0f; h.v = is.hit ? is.v : 0.0f;
       h.instance = is.hit ? (int32_t)is.instance_id : -1;
@@ -1449,7 +1663,7 @@ float orc_lut_sample(const orc_scene* sc, int which, float cx, float cy, float c
 //   out_sample: wi[3], f[3], Le[3], pdf, flags(as float)  = 11 floats
 void orc_bsdf_sample(const orc_scene* sc, const pt_material_gpu* mat, const float wo[3], const float r[4], const float rc[2],
                      float out_sample[11]) {
-  ShadingContext ctx(*mat, sc->idt);
+  ShadingContext ctx(*mat, float2{0.0f, 0.0f}, sc->idt, sc->textures);
   BSDF bsdf(ctx, sc->constants.flags, sc->luts);
   Sample s = bsdf.sample(f3(wo[0], wo[1], wo[2]), {r[0], r[1], r[2], r[3]}, {rc[0], rc[1]});
   float o[11] = {s.wi.x, s.wi.y, s.wi.z, s.f.x, s.f.y, s.f.z, s.Le.x, s.Le.y, s.Le.z, s.pdf, (float)s.flags};
@@ -1457,7 +1671,7 @@ void orc_bsdf_sample(const orc_scene* sc, const pt_material_gpu* mat, const floa
 }
 //   out_eval: f[3], pdf = 4 floats
 void orc_bsdf_eval(const orc_scene* sc, const pt_material_gpu* mat, const float wo[3], const float wi[3], float out_eval[4]) {
-  ShadingContext ctx(*mat, sc->idt);
+  ShadingContext ctx(*mat, float2{0.0f, 0.0f}, sc->idt, sc->textures);
   BSDF bsdf(ctx, sc->constants.flags, sc->luts);
   Eval e = bsdf.eval(f3(wo[0], wo[1], wo[2]), f3(wi[0], wi[1], wi[2]));
   out_eval[0] = e.f.x; out_eval[1] = e.f.y; out_eval[2] = e.f.z; out_eval[3] = e.pdf;

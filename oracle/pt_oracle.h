@@ -22,6 +22,7 @@ orc_scene* orc_scene_create(const pt_scene_snapshot* snap, const pt_render_param
                             uint64_t lut_size, int use_bvh);
 void orc_scene_destroy(orc_scene* sc);
 int orc_get_constants(const orc_scene* sc, pt_constants* out);
+int orc_get_env_alias(const orc_scene* sc, pt_alias_entry* out, uint64_t capacity, uint64_t* count);
 int orc_get_lights(const orc_scene* sc, pt_area_light* out, uint32_t capacity, uint32_t* count);
 int orc_render(orc_scene* sc, uint32_t first_sample, uint32_t nsamples, float* acc, uint32_t acc_n0, int threads,
                int count_traversal);
@@ -44,6 +45,11 @@ float orc_log2(float x);
 float orc_exp2(float x);
 void orc_sample_cosine_hemisphere(float u0, float u1, float out[3]);
 void orc_sample_tri_uniform(float u0, float u1, float out[2]);
+float orc_atan2(float y, float x);
+float orc_acos(float x);
+void orc_tex_sample(const orc_scene* sc, int texture, float u, float v, float out[4]);
+void orc_ray_dir_to_uv(const float dir[3], float out[2]);
+void orc_uv_to_ray_dir(const float uv[2], float out[3]);
 float orc_lut_sample(const orc_scene* sc, int which, float cx, float cy, float cz);
 void orc_bsdf_sample(const orc_scene* sc, const pt_material_gpu* mat, const float wo[3], const float r[4], const float rc[2],
                      float out_sample[11]);

@@ -7,7 +7,7 @@ library is missing or cannot find a device, loading / pt_create raises.
 import ctypes as C
 import os
 
-PT_ABI_VERSION = 1
+PT_ABI_VERSION = 2
 
 # renderer_pt.hpp:21-26
 STATUS_BLOCKED, STATUS_READY, STATUS_BUSY, STATUS_DONE = 0, 1, 4, 8
@@ -69,10 +69,25 @@ class Colorspace(C.Structure):
     _fields_ = [("r", C.c_float * 2), ("g", C.c_float * 2), ("b", C.c_float * 2), ("w", C.c_float * 2)]
 
 
+TEX_RGBA8_SRGB, TEX_RGBA8, TEX_RG8, TEX_R8, TEX_RGBA32F = 0, 1, 2, 3, 4
+
+
+class Texture(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class AliasEntry(C.Structure):
+    _fields_ = [("pdf", C.c_float), ("p", C.c_float), ("aliasIdx", C.c_uint32)]
+
+
+ALIAS_DTYPE = [("pdf", "f4"), ("p", "f4"), ("aliasIdx", "u4")]  # numpy view of pt_alias_entry
+
+
 class SceneSnapshot(C.Structure):
     _fields_ = [
         ("meshes", C.c_void_p), ("mesh_count", C.c_uint32), ("instance_count", C.c_uint32),
         ("instances", C.c_void_p), ("instance_materials", C.c_void_p), ("camera", Camera),
+        ("textures", C.c_void_p), ("texture_count", C.c_uint32), ("env_texture", C.c_int32), ("env_alias", C.c_void_p),
     ]
 
 
@@ -187,6 +202,7 @@ SYMBOLS = [
     ("pt_last_error", C.c_char_p, []),
     ("pt_get_constants", C.c_int, [C.c_void_p, C.POINTER(Constants)]),
     ("pt_get_lights", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    ("pt_get_env_alias", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("pt_trace_primary", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     ("pt_debug_sample", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("pt_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),

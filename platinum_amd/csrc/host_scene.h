@@ -3,6 +3,8 @@
 //   rebuildResourceBuffers   renderer_pt.cpp:448-651   (per-mesh / per-instance tables, MaterialGPU flags)
 //   updateConstants          renderer_pt.cpp:965-1021  (camera frame, idt)
 //   rebuildLightData         renderer_pt.cpp:838-917   (area-light table, cumulative power)
+//   texture decode           (the MTLTexture pixel formats the reference samples: DESIGN.md "Texture contract")
+//   rebuildAliasTable        core/environment.cpp:5-91 (environment importance table)
 // Plain C++ (no HIP) so the tests/emu debugging harness can build it for the host.
 #pragma once
 #include <algorithm>
@@ -23,6 +25,11 @@ struct HostScene {
   std::vector<InstanceInfo> instances;
   std::vector<pt_material_gpu> materials;
   std::vector<pt_area_light> lights;
+  std::vector<vec4> tex_pixels;          // every texture decoded to linear float4, back to back
+  std::vector<TexInfo> textures;
+  std::vector<pt_alias_entry> env_alias;
+  int32_t env_texture = -1;
+  bool has_alpha = false;
   pt_constants constants{};
   Mat3 idt{};
   uint32_t tri_count = 0;
@@ -106,6 +113,78 @@ inline pt_float3 to_pt(vec3 v) { return {v.x, v.y, v.z, 0.0f}; }
 inline vec3 from_pt(const pt_float3& v) { return v3(v.x, v.y, v.z); }
 
 
+// Texel decode (DESIGN.md "Texture contract"): UNORM8 -> i/255; sRGB8 colour channels through the piecewise sRGB EOTF
+// evaluated in double and rounded once; R8 -> (r,0,0,1); RG8 -> (r,g,0,1); RGBA32F verbatim.
+inline int decode_textures(const pt_scene_snapshot* scene, HostScene* out, std::string* err) {
+  float eotf[256];
+  for (int i = 0; i < 256; i++) {
+    const double c = (double)i / 255.0;
+    eotf[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
+  }
+  size_t total = 0;
+  for (uint32_t t = 0; t < scene->texture_count; t++) {
+    const pt_texture& tx = scene->textures[t];
+    if (!tx.pixels || tx.width == 0 || tx.height == 0 || tx.width > 32768 || tx.height > 32768)
+      return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "texture: null pixels or bad size");
+    if (tx.format < PT_TEX_RGBA8_SRGB || tx.format > PT_TEX_RGBA32F) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "texture: unknown format");
+    total += (size_t)tx.width * tx.height;
+  }
+  if (total >= (1ull << 32)) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "textures: more than 2^32 texels");
+  out->tex_pixels.resize(total);
+  out->textures.resize(scene->texture_count);
+  size_t base = 0;
+  for (uint32_t t = 0; t < scene->texture_count; t++) {
+    const pt_texture& tx = scene->textures[t];
+    const size_t n = (size_t)tx.width * tx.height;
+    out->textures[t] = {(uint32_t)base, tx.width, tx.height, 0};
+    vec4* dst = &out->tex_pixels[base];
+    const uint8_t* b = (const uint8_t*)tx.pixels;
+    if (tx.format == PT_TEX_RGBA32F) {
+      memcpy(dst, tx.pixels, n * sizeof(vec4));
+    } else if (tx.format == PT_TEX_RGBA8_SRGB) {
+      for (size_t i = 0; i < n; i++) dst[i] = vec4{eotf[b[4 * i]], eotf[b[4 * i + 1]], eotf[b[4 * i + 2]], (float)b[4 * i + 3] / 255.0f};
+    } else if (tx.format == PT_TEX_RGBA8) {
+      for (size_t i = 0; i < n; i++)
+        dst[i] = vec4{(float)b[4 * i] / 255.0f, (float)b[4 * i + 1] / 255.0f, (float)b[4 * i + 2] / 255.0f, (float)b[4 * i + 3] / 255.0f};
+    } else if (tx.format == PT_TEX_RG8) {
+      for (size_t i = 0; i < n; i++) dst[i] = vec4{(float)b[2 * i] / 255.0f, (float)b[2 * i + 1] / 255.0f, 0.0f, 1.0f};
+    } else {
+      for (size_t i = 0; i < n; i++) dst[i] = vec4{(float)b[i] / 255.0f, 0.0f, 0.0f, 1.0f};
+    }
+    base += n;
+  }
+  return PT_OK;
+}
+
+// Environment::rebuildAliasTable (core/environment.cpp:5-91): importance = BT.709 luma of each texel, normalised to mean 1
+// (that is EnvironmentLight::alias[i].pdf), then Vose's alias method with the reference's two LIFO work lists.
+inline void build_env_alias(const vec4* px, size_t n, std::vector<pt_alias_entry>* table) {
+  table->assign(n, pt_alias_entry{0.0f, 0.0f, 0u});
+  std::vector<float> q(n);
+  float sum = 0.0f;
+  for (size_t i = 0; i < n; i++) {
+    q[i] = dot(v3(px[i].x, px[i].y, px[i].z), v3(0.2126f, 0.7152f, 0.0722f));
+    sum += q[i];
+  }
+  const float scale = (float)n / sum;
+  std::vector<size_t> under, over;
+  for (size_t i = 0; i < n; i++) {
+    q[i] *= scale;
+    (*table)[i].pdf = q[i];
+    (q[i] < 1.0f ? under : over).push_back(i);
+  }
+  while (!under.empty() && !over.empty()) {
+    const size_t lo = under.back(), hi = over.back();
+    under.pop_back(); over.pop_back();
+    (*table)[lo].p = q[lo];
+    (*table)[lo].aliasIdx = (uint32_t)hi;
+    q[hi] = (q[hi] + q[lo]) - 1.0f;
+    (q[hi] < 1.0f ? under : over).push_back(hi);
+  }
+  for (size_t i : over) (*table)[i].p = 1.0f;
+  for (size_t i : under) (*table)[i].p = 1.0f;
+}
+
 inline int build_host_scene(const pt_scene_snapshot* scene, const pt_render_params* p, uint32_t lut_w_E, uint32_t lut_w_Eavg,
                             HostScene* out, std::string* err) {
   // ---- flatten the snapshot (rebuildResourceBuffers, renderer_pt.cpp:448-651) ----
@@ -138,6 +217,21 @@ inline int build_host_scene(const pt_scene_snapshot* scene, const pt_render_para
         if (pm.indices[k] >= pm.vertex_count) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "mesh: vertex index out of range");
     }
   }
+  // ---- textures and the environment light (N3) ----
+  if (scene->texture_count && !scene->textures) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "scene: null texture array");
+  if (const int rc = decode_textures(scene, out, err)) return rc;
+  out->env_texture = -1;
+  out->env_alias.clear();
+  if (scene->env_texture >= 0) {
+    if ((uint32_t)scene->env_texture >= scene->texture_count) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "scene: env_texture out of range");
+    out->env_texture = scene->env_texture;
+    const TexInfo& et = out->textures[out->env_texture];
+    const size_t n = (size_t)et.w * et.h;
+    if (scene->env_alias) out->env_alias.assign(scene->env_alias, scene->env_alias + n);  // the host's own table, verbatim
+    else build_env_alias(&out->tex_pixels[et.offset], n, &out->env_alias);
+  }
+  out->has_alpha = false;
+
   std::vector<InstanceInfo>& instances = out->instances;
   instances.assign(scene->instance_count, InstanceInfo{});
   std::vector<pt_material_gpu>& materials = out->materials;
@@ -159,13 +253,17 @@ inline int build_host_scene(const pt_scene_snapshot* scene, const pt_render_para
       if (pm.material_slots[t] >= im.material_count) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "instance: material slot out of range");
     for (uint32_t k = 0; k < im.material_count; k++) {
       pt_material_gpu mat = im.materials[k];
-      if (mat.baseTextureId >= 0 || mat.rmTextureId >= 0 || mat.transmissionTextureId >= 0 || mat.clearcoatTextureId >= 0 ||
-          mat.emissionTextureId >= 0 || mat.normalTextureId >= 0)
-        return hs_fail(err, PT_ERR_UNSUPPORTED, "textures (SURVEY §8f N3) are not part of this ABI version: texture ids must be -1");
+      const int32_t ids[6] = {mat.baseTextureId, mat.rmTextureId, mat.transmissionTextureId, mat.clearcoatTextureId,
+                              mat.emissionTextureId, mat.normalTextureId};
+      for (int32_t id : ids)
+        if (id >= 0 && (uint32_t)id >= scene->texture_count) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "material: texture id out of range");
       // renderer_pt.cpp:626-633: the Renderer derives these two flags when it fills MaterialGPU
+      // (Material::isEmissive, core/material.hpp:44-47: non-zero emission or an emission texture)
       const vec3 e = from_pt(mat.emission) * mat.emissionStrength;
-      if (length_squared(e) > 0.0f) mat.flags |= PT_MATERIAL_EMISSIVE;
+      if (length_squared(e) > 0.0f || mat.emissionTextureId >= 0) mat.flags |= PT_MATERIAL_EMISSIVE;
       if (mat.anisotropy != 0.0f) mat.flags |= PT_MATERIAL_ANISOTROPIC;
+      // renderer_pt.cpp:714-729: an instance with any alpha-tested material is built non-opaque
+      if (mat.flags & PT_MATERIAL_USE_ALPHA) { instances[i].flags |= kInstanceNonOpaque; out->has_alpha = true; }
       materials.push_back(mat);
     }
     tri_total += pm.triangle_count;
@@ -241,7 +339,7 @@ inline int build_host_scene(const pt_scene_snapshot* scene, const pt_render_para
     }
   }
   C.lightCount = (uint32_t)out->lights.size();
-  C.envLightCount = 0;
+  C.envLightCount = out->env_texture >= 0 ? 1 : 0;  // one EnvironmentLight per scene environment (renderer_pt.cpp:919-938)
   C.totalLightPower = totalPower;
 
   return PT_OK;

@@ -236,7 +236,9 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DeviceScene S, PathSta
       ray = fresh;
       const vec4 o4 = st.rayO[ray];
       const vec4 d4 = st.rayD[ray];
-      if (trav_init(S, ts, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 1e-3f, kInf, stack, false, COUNT ? &tc : nullptr)) finish();
+      float ir = 0.0f;  // alpha-test payload: the sample drawn before `intersect` (kernel.metal:510), only needed with cut-outs
+      if (S.has_alpha) ir = Halton{S.halton, f2u(st.att[ray].w), f2u(d4.w) & kMetaDimMask}.sample1d();
+      if (trav_init(S, ts, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 1e-3f, kInf, ir, stack, false, COUNT ? &tc : nullptr)) finish();
     }
     if (__ballot(ray != kInvalidRef) == 0) {
       if (src.exhausted && src.pool_next == src.pool_end) break;
@@ -279,7 +281,20 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(DeviceScene S,
     if (k < n) {
       const vec4 h4 = hit[i];
       const uint32_t tri = f2u(h4.w);
-      if (tri != kInvalidRef) {  // a miss adds attenuation * backgroundColor (= 0, defs.metal:21) and ends the path
+      if (tri == kInvalidRef) {
+        // a miss ends the path; it adds the environment's radiance if there is one (kernel.metal:517-539), then
+        // attenuation * backgroundColor (= 0, defs.metal:21)
+        if (S.env_texture >= 0) {
+          const vec4 o4 = sin.rayO[i];
+          const vec4 d4 = sin.rayD[i];
+          const vec4 a4 = sin.att[i];
+          const vec3 Le = stage_miss(S, v3(d4.x, d4.y, d4.z), v3(a4.x, a4.y, a4.z), bounce, o4.w, (f2u(d4.w) & kMetaSpecular) != 0);
+          const uint32_t mpid = sin.pid[i];
+          vec4 L = Lbuf[mpid];
+          L.x += Le.x; L.y += Le.y; L.z += Le.z;
+          Lbuf[mpid] = L;
+        }
+      } else {
         const vec4 o4 = sin.rayO[i];
         const vec4 d4 = sin.rayD[i];
         const vec4 a4 = sin.att[i];
@@ -328,7 +343,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(DeviceScene S,
         const uint32_t j = seg_slot(seg.nwaves, w, n_shadow + wave_prefix(m));
         sq.o[j] = vec4{out.shadow_o.x, out.shadow_o.y, out.shadow_o.z, out.shadow_tmax};
         sq.d[j] = vec4{out.shadow_d.x, out.shadow_d.y, out.shadow_d.z, u2f(pid)};
-        sq.contrib[j] = vec4{out.shadow_contrib.x, out.shadow_contrib.y, out.shadow_contrib.z, 0.0f};
+        sq.contrib[j] = vec4{out.shadow_contrib.x, out.shadow_contrib.y, out.shadow_contrib.z, out.shadow_payload};
       }
       n_shadow += (uint32_t)__popcll(m);
     }
@@ -381,7 +396,8 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow(DeviceScene S, ShadowQu
       const vec4 o4 = sq.o[ray];
       const vec4 d4 = sq.d[ray];
       pid = f2u(d4.w);
-      if (trav_init(S, ts, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 1e-3f, o4.w, stack, true, COUNT ? &tc : nullptr)) finish();
+      const float ir = S.has_alpha ? sq.contrib[ray].w : 0.0f;  // kernel.metal:625
+      if (trav_init(S, ts, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 1e-3f, o4.w, ir, stack, true, COUNT ? &tc : nullptr)) finish();
     }
     if (__ballot(ray != kInvalidRef) == 0) {
       if (src.exhausted && src.pool_next == src.pool_end) break;

@@ -51,14 +51,35 @@ PT_HD float lut3(const Lut& l, float cx, float cy, float cz) {
   return a + (b - a) * az.w;
 }
 
-// defs.metal:283-299, bsdf.metal:12-43 (texture fetches: SURVEY §8f N3, ids are -1 in this ABI version)
+// defs.metal:283-299, bsdf.metal:12-43
 struct ShadingContext {
   vec3 albedo;
   float roughness, metallic, transmission, clearcoat, clearcoatRoughness, anisotropy, ior;
   int flags;
   vec3 emission;
 };
-PT_HD ShadingContext make_shading_context(const pt_material_gpu& mat, const Mat3& idt) {
+// sampler(address::repeat, filter::linear) on a decoded float4 texture (filtering contract: DESIGN.md §2)
+PT_HD int tex_wrap(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
+PT_HD vec4 tex_sample(const DeviceScene& S, int id, vec2 uv) {
+  const TexInfo t = S.textures[id];
+  const float fx = uv.x * (float)t.w - 0.5f, fy = uv.y * (float)t.h - 0.5f;
+  const float x0f = floorf(fx), y0f = floorf(fy);
+  const float wx = fx - x0f, wy = fy - y0f;
+  const int x0 = tex_wrap((int)x0f, (int)t.w), x1 = tex_wrap((int)x0f + 1, (int)t.w);
+  const int y0 = tex_wrap((int)y0f, (int)t.h), y1 = tex_wrap((int)y0f + 1, (int)t.h);
+  const vec4* __restrict__ px = S.tex_pixels + t.offset;
+  const vec4 p00 = px[(size_t)y0 * t.w + x0], p01 = px[(size_t)y0 * t.w + x1];
+  const vec4 p10 = px[(size_t)y1 * t.w + x0], p11 = px[(size_t)y1 * t.w + x1];
+  vec4 o;
+  { const float a = p00.x + (p01.x - p00.x) * wx, b = p10.x + (p11.x - p10.x) * wx; o.x = a + (b - a) * wy; }
+  { const float a = p00.y + (p01.y - p00.y) * wx, b = p10.y + (p11.y - p10.y) * wx; o.y = a + (b - a) * wy; }
+  { const float a = p00.z + (p01.z - p00.z) * wx, b = p10.z + (p11.z - p10.z) * wx; o.z = a + (b - a) * wy; }
+  { const float a = p00.w + (p01.w - p00.w) * wx, b = p10.w + (p11.w - p10.w) * wx; o.w = a + (b - a) * wy; }
+  return o;
+}
+
+PT_HD ShadingContext make_shading_context(const DeviceScene& S, const pt_material_gpu& mat, vec2 uv) {
+  const Mat3& idt = S.idt;
   ShadingContext c;
   c.albedo = v3(mat.baseColor[0], mat.baseColor[1], mat.baseColor[2]);
   c.emission = v3(mat.emission.x, mat.emission.y, mat.emission.z);
@@ -70,6 +91,15 @@ PT_HD ShadingContext make_shading_context(const pt_material_gpu& mat, const Mat3
   c.anisotropy = mat.anisotropy;
   c.ior = mat.ior;
   c.flags = mat.flags;
+  if (mat.baseTextureId >= 0) { const vec4 t = tex_sample(S, mat.baseTextureId, uv); c.albedo = v3(t.x, t.y, t.z); }  // bsdf.metal:25-26
+  if (mat.emissionTextureId >= 0) { const vec4 t = tex_sample(S, mat.emissionTextureId, uv); c.emission = c.emission * v3(t.x, t.y, t.z); }
+  if (mat.transmissionTextureId >= 0) c.transmission = tex_sample(S, mat.transmissionTextureId, uv).x;
+  if (mat.clearcoatTextureId >= 0) c.clearcoat = tex_sample(S, mat.clearcoatTextureId, uv).x;
+  if (mat.rmTextureId >= 0) {  // bsdf.metal:33-37
+    const vec4 rm = tex_sample(S, mat.rmTextureId, uv);
+    c.roughness = c.roughness * rm.x;
+    c.metallic = c.metallic * rm.y;
+  }
   c.albedo = mul(idt, c.albedo);
   c.emission = mul(idt, c.emission);
   c.emission = c.emission * mat.emissionStrength;

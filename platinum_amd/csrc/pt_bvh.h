@@ -9,7 +9,7 @@
 // depend on the BVH: the slab test is conservative (boxes are inflated at build time, the comparison carries
 // slack), so traversal visits a superset of the triangles that can be hit.
 #pragma once
-#include "pt_device.h"
+#include "pt_bsdf.h"
 
 namespace pt {
 
@@ -91,8 +91,28 @@ struct TravState {
   float tmin;
   RayHit best;     // best.t doubles as the current far limit
   uint32_t cur;    // node to visit next
+  float payload;   // the `ir` sample handed to the alpha-test intersection function (kernel.metal:510, 625)
   TraversalStack st;
 };
+
+// intersections.metal:8-39 alphaTestIntersectionFunction: runs for every candidate hit on a non-opaque instance;
+// the hit counts iff alpha(baseColor.a x baseTexture.a at the interpolated uv) > payload.
+PT_HD bool alpha_test(const DeviceScene& S, uint32_t instanceIdx, uint32_t prim, float u, float v, float r) {
+  const InstanceInfo& inst = S.instances[instanceIdx];
+  const MeshInfo mesh = S.meshes[inst.mesh];
+  const pt_material_gpu& material = S.materials[inst.material_base + S.slots[mesh.tri_base + prim]];
+  float alpha = material.baseColor[3];
+  if (material.baseTextureId >= 0) {
+    const uint32_t* __restrict__ idx = &S.indices[3 * (size_t)(mesh.tri_base + prim)];
+    const float* t0 = S.vdata[mesh.vertex_base + idx[0]].texCoords;
+    const float* t1 = S.vdata[mesh.vertex_base + idx[1]].texCoords;
+    const float* t2 = S.vdata[mesh.vertex_base + idx[2]].texCoords;
+    const float w = 1.0f - u - v;
+    const vec2 uv = {(w * t0[0] + u * t1[0]) + v * t2[0], (w * t0[1] + u * t1[1]) + v * t2[1]};
+    alpha = alpha * tex_sample(S, material.baseTextureId, uv).w;
+  }
+  return alpha > r;
+}
 
 PT_HD void trav_leaf(const DeviceScene& S, TravState& ts, uint32_t ref, bool any, bool* finished, TraversalCount* cnt) {
   const uint32_t ti = ref & ~kLeafBit;
@@ -100,6 +120,7 @@ PT_HD void trav_leaf(const DeviceScene& S, TravState& ts, uint32_t ref, bool any
   if (cnt) cnt->tris++;
   float t, u, v;
   if (!intersect_triangle(ts.o, ts.d, ts.tmin, ts.best.t, tr, &t, &u, &v)) return;
+  if (S.has_alpha && (S.instances[tr.inst].flags & kInstanceNonOpaque) && !alpha_test(S, tr.inst, tr.prim, u, v, ts.payload)) return;
   if (any) {
     ts.best.tri = ti;
     *finished = true;
@@ -112,9 +133,9 @@ PT_HD void trav_leaf(const DeviceScene& S, TravState& ts, uint32_t ref, bool any
 }
 
 // Returns true when the ray is finished (ts.best holds the answer). `st` must be the lane's stack.
-PT_HD bool trav_init(const DeviceScene& S, TravState& ts, vec3 o, vec3 d, float tmin, float tmax, TraversalStack st, bool any,
-                     TraversalCount* cnt) {
-  ts.o = o; ts.d = d; ts.tmin = tmin;
+PT_HD bool trav_init(const DeviceScene& S, TravState& ts, vec3 o, vec3 d, float tmin, float tmax, float payload, TraversalStack st,
+                     bool any, TraversalCount* cnt) {
+  ts.o = o; ts.d = d; ts.tmin = tmin; ts.payload = payload;
   ts.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   ts.best.t = tmax; ts.best.u = ts.best.v = 0.0f; ts.best.tri = kInvalidRef; ts.best.gid = kInvalidRef;
   ts.st = st;
@@ -260,10 +281,10 @@ PT_HD bool trav_step(const DeviceScene& S, TravState& ts, TraversalCount* cnt) {
 }
 
 template <bool ANY, bool COUNT>
-PT_HD RayHit traverse(const DeviceScene& S, vec3 o, vec3 d, float tmin, float tmax, TraversalStack st,
+PT_HD RayHit traverse(const DeviceScene& S, vec3 o, vec3 d, float tmin, float tmax, float payload, TraversalStack st,
                       TraversalCount* cnt) {
   TravState ts;
-  if (trav_init(S, ts, o, d, tmin, tmax, st, ANY, COUNT ? cnt : nullptr)) return ts.best;
+  if (trav_init(S, ts, o, d, tmin, tmax, payload, st, ANY, COUNT ? cnt : nullptr)) return ts.best;
   while (!trav_step<ANY, COUNT>(S, ts, cnt)) {}
   return ts.best;
 }

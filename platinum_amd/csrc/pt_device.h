@@ -23,8 +23,9 @@ struct alignas(16) InstanceInfo {  // MTLAccelerationStructureInstanceDescriptor
   uint32_t mesh;                     // accelerationStructureIndex
   uint32_t material_base;            // into materials[]: this instance's MaterialGPU array
   uint32_t tri_global_base;          // global id of this instance's first flattened triangle
-  uint32_t _pad;
+  uint32_t flags;                    // kInstanceNonOpaque: candidates go through the alpha test (renderer_pt.cpp:714-729)
 };
+constexpr uint32_t kInstanceNonOpaque = 1u;
 static_assert(sizeof(InstanceInfo) == 64, "InstanceInfo");
 
 // ---- BVH -------------------------------------------------------------------------------------------------------
@@ -77,6 +78,9 @@ constexpr int kHaltonDims = 620;
 struct Lut { const float* d; int w, h, depth; };
 struct LutSet { Lut E, Eavg, EMs, EavgMs, ETransIn, ETransOut; };  // the two *avgTrans tables are never sampled
 
+// ---- scene textures: decoded to linear float4 at upload, sampled with repeat + bilinear ---------------
+struct TexInfo { uint32_t offset, w, h, _pad; };  // offset into DeviceScene::tex_pixels
+
 struct Mat3 { vec3 c0, c1, c2; };
 PT_HD vec3 mul(const Mat3& m, vec3 v) { return (m.c0 * v.x + m.c1 * v.y) + m.c2 * v.z; }
 
@@ -96,6 +100,12 @@ struct DeviceScene {
   uint32_t root_ref;       // kLeafBit|0 for a single-triangle scene, 0 otherwise, kInvalidRef when empty
   const HaltonEntry* halton;
   LutSet luts;
+  const vec4* tex_pixels;
+  const TexInfo* textures;
+  const pt_alias_entry* env_alias;  // EnvironmentLight::alias (pt_shader_defs.hpp:70-73)
+  int32_t env_texture;              // -1: no environment light
+  uint32_t envLightCount;           // 0 or 1
+  uint32_t has_alpha;               // any non-opaque instance: the trace kernels evaluate the alpha-test payload
   // Constants (pt_shader_defs.hpp:105-115) — the fields the kernels read
   pt_camera_data camera;
   Mat3 idt;

@@ -75,6 +75,28 @@ PT_HD void sincos_det(float x, float* s_out, float* c_out) {
 }
 PT_HD float cos_det(float x) { float s, c; sincos_det(x, &s, &c); return c; }
 
+// atan: cephes atanf reduction (tan(3pi/8), tan(pi/8)) + degree-9 odd polynomial; atan2 by quadrant; acos through atan2.
+PT_HD float atan_det(float xx) {
+  float x = fabsf(xx), y;
+  if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+  else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+  else y = 0.0f;
+  const float z = x * x;
+  y = y + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x);
+  return xx < 0.0f ? -y : y;
+}
+PT_HD float atan2_det(float y, float x) {
+  if (x > 0.0f) return atan_det(y / x);
+  if (x < 0.0f) return y >= 0.0f ? atan_det(y / x) + kPi : atan_det(y / x) - kPi;
+  if (y > 0.0f) return 1.5707963267948966f;
+  if (y < 0.0f) return -1.5707963267948966f;
+  return 0.0f;
+}
+PT_HD float acos_det(float x) {
+  x = fminf(fmaxf(x, -1.0f), 1.0f);
+  return atan2_det(sqrtf((1.0f - x) * (1.0f + x)), x);
+}
+
 PT_HD float log2_det(float x) {
   uint32_t bits = f2u(x);
   int e = (int)((bits >> 23) & 0xff) - 126;

@@ -7,7 +7,6 @@
 // The callers (kernels.hip) own queues, compaction and memory traffic; these functions are pure per-path math so
 // that tests/emu can run them on the host for debugging.
 #pragma once
-#include "pt_bsdf.h"
 #include "pt_bvh.h"
 
 namespace pt {
@@ -95,12 +94,61 @@ struct ShadeOut {
   vec3 shadow_o, shadow_d;
   float shadow_tmax;
   vec3 shadow_contrib; // attenuation * Ld, to add if the shadow ray is unoccluded
+  float shadow_payload;
   bool alive;          // path continues to bounce + 1
   vec3 next_o, next_d, next_att;
   float next_pdf;
   bool next_specular;
   uint32_t dim;
 };
+
+// kernel.metal:20-25 rayDirToUv, :27-34 uvToRayDir
+PT_HD vec2 rayDirToUv(vec3 dir) {
+  const float phi = atan2_det(-dir.z, -dir.x);
+  const float theta = acos_det(dir.y);
+  return {phi / (2.0f * kPi), theta / kPi};
+}
+PT_HD vec3 uvToRayDir(vec2 uv) {
+  float y, r, cosPhi, sinPhi;
+  sincos_det(uv.y * kPi, &r, &y);
+  sincos_det(uv.x * 2.0f * kPi, &sinPhi, &cosPhi);
+  return normalize(v3(-cosPhi * r, y, -sinPhi * r));
+}
+
+struct EnvSample { vec3 Li, wi; float pdf; };
+PT_HD EnvSample sample_environment(const DeviceScene& S, vec2 r) {  // kernel.metal:440-467
+  const TexInfo t = S.textures[S.env_texture];
+  const uint64_t w = t.w, h = t.h, n = w * h;
+  uint64_t i = (uint64_t)(r.x * (float)n);
+  if (i > n - 1) i = n - 1;
+  if (r.y >= S.env_alias[i].p) i = S.env_alias[i].aliasIdx;
+  const uint64_t x = i % w, y = i / w;
+  const vec2 uv = {(float)x / (float)w, (float)y / (float)h};
+  const vec4 Le = tex_sample(S, S.env_texture, uv);
+  EnvSample es;
+  es.Li = v3(Le.x, Le.y, Le.z);
+  es.wi = uvToRayDir(uv);
+  es.pdf = S.env_alias[i].pdf / (4.0f * kPi);
+  return es;
+}
+
+// Ray miss with an environment light (kernel.metal:517-539; :299-311 for the simple integrator): returns the radiance
+// to add (already multiplied by the attenuation and the MIS weight).
+PT_HD vec3 stage_miss(const DeviceScene& S, vec3 d, vec3 att, uint32_t bounce, float lastPdf, bool lastSpecular) {
+  const TexInfo t = S.textures[S.env_texture];
+  const vec2 uv = rayDirToUv(d);
+  const vec4 s = tex_sample(S, S.env_texture, uv);
+  const vec3 Le = v3(s.x, s.y, s.z);
+  if (S.integrator != PT_INTEGRATOR_MIS || bounce == 0 || lastSpecular) return att * Le;
+  // uint32_t x = w * uv.x: a negative product (half the sphere, atan2 range) converts to 0; indices are clamped
+  const float fxw = (float)t.w * uv.x, fyh = (float)t.h * uv.y;
+  uint32_t x = fxw > 0.0f ? (uint32_t)fxw : 0u, y = fyh > 0.0f ? (uint32_t)fyh : 0u;
+  x = x < t.w - 1 ? x : t.w - 1;
+  y = y < t.h - 1 ? y : t.h - 1;
+  const float lightPdf = S.env_alias[(size_t)y * t.w + x].pdf * 0.25f * 0.318309886183790671538f;
+  const float bsdfWeight = lastPdf / (lastPdf + lightPdf);
+  return att * bsdfWeight * Le;
+}
 
 // kernel.metal:379-394
 PT_HD uint32_t sampleLightPower(const DeviceScene& S, float r) {
@@ -143,7 +191,9 @@ PT_HD ShadeOut stage_shade(const DeviceScene& S, const ShadeIn& in) {
   const vec3 surfaceTangent = interpolate3(v3(vd0.tangent[0], vd0.tangent[1], vd0.tangent[2]),
                                            v3(vd1.tangent[0], vd1.tangent[1], vd1.tangent[2]),
                                            v3(vd2.tangent[0], vd2.tangent[1], vd2.tangent[2]), in.u, in.v);
-  // surfaceUV (kernel.metal:143) only feeds texture fetches — a "next" row
+  const float wb = 1.0f - in.u - in.v;  // interpolate(vertexTexCoords, bary), kernel.metal:143
+  const vec2 surfaceUV = {(wb * vd0.texCoords[0] + in.u * vd1.texCoords[0]) + in.v * vd2.texCoords[0],
+                          (wb * vd0.texCoords[1] + in.u * vd1.texCoords[1]) + in.v * vd2.texCoords[1]};
   const vec3 geometricNormal = normalize(cross(p1 - p0, p2 - p0));
 
   const Xform objectToWorld = load_xform(inst);
@@ -151,7 +201,12 @@ PT_HD ShadeOut stage_shade(const DeviceScene& S, const ShadeIn& in) {
   const vec3 wsSurfaceNormal = normalize(transformVec(surfaceNormal, objectToWorld));
   const vec3 wsSurfaceTangent = normalize(transformVec(surfaceTangent, objectToWorld));
   const vec3 wsGeometricNormal = normalize(transformVec(geometricNormal, objectToWorld));
-  const Frame frame = frame_from_nt(wsSurfaceNormal, wsSurfaceTangent, tangentSign);
+  Frame frame = frame_from_nt(wsSurfaceNormal, wsSurfaceTangent, tangentSign);
+  if (material.normalTextureId >= 0) {  // kernel.metal:166-175
+    const vec4 t = tex_sample(S, material.normalTextureId, surfaceUV);
+    const vec3 sampledNormal = v3(t.x, t.y, t.z) * 2.0f - v3(1.0f);
+    frame = frame_from_normal(frame.localToWorld(sampledNormal));
+  }
   const vec3 wo = frame.worldToLocal(-in.d);
 
   // ---- BSDF sample (kernel.metal:550-556) ----
@@ -159,7 +214,7 @@ PT_HD ShadeOut stage_shade(const DeviceScene& S, const ShadeIn& in) {
   const float r2 = halton.sample1d();
   const float r3 = halton.sample1d();
   const vec2 rc = halton.sample2d();
-  const ShadingContext ctx = make_shading_context(material, S.idt);
+  const ShadingContext ctx = make_shading_context(S, material, surfaceUV);
   const BSDF bsdf(ctx, S.flags, S.luts);
   const BsdfSample sample = bsdf.sample(wo, vec4{r01.x, r01.y, r2, r3}, rc);
 
@@ -181,31 +236,45 @@ PT_HD ShadeOut stage_shade(const DeviceScene& S, const ShadeIn& in) {
   if (mis && (ctx.roughness > 0.0f || ctx.metallic + ctx.transmission < 1.0f)) {
     const vec2 rl = halton.sample2d();
     float rz = halton.sample1d();
-    if (S.lightCount > 0) {  // no env lights in this ABI version => pInfinite = 0 (kernel.metal:593-596)
-      const float pInfinite = 0.0f;
-      rz = (rz - pInfinite) / (1.0f - pInfinite);
-      const pt_area_light light = S.lights[sampleLightPower(S, rz)];
-      const float pLight = (1.0f - pInfinite) * light.power / S.totalLightPower;
-      // sampleAreaLight (kernel.metal:407-435)
-      const InstanceInfo linst = S.instances[light.instanceIdx];
-      const uint32_t vb = S.meshes[linst.mesh].vertex_base;
-      const vec3 q0 = ld3(S.positions[vb + light.indices[0]]);
-      const vec3 q1 = ld3(S.positions[vb + light.indices[1]]);
-      const vec3 q2 = ld3(S.positions[vb + light.indices[2]]);
-      const vec2 sc = sampleTriUniform(rl);
-      const Xform lx = load_xform(linst);
-      const vec3 osNormal = cross(q1 - q0, q2 - q0);
-      const vec3 lpos = transformPoint(interpolate3(q0, q1, q2, sc.x, sc.y), lx);
-      const vec3 lnormal = normalize(transformVec(osNormal, lx));
-      const vec3 lwi = normalize(lpos - hitPos);
-      const float lpdf = length_squared(lpos - hitPos) / (fabsf(dot(lnormal, lwi)) * light.area);
+    // kernel.metal:590-616. Without any light the reference indexes envLights[0] out of bounds (UB): NEE is skipped then,
+    // the three dimensions are still consumed.
+    const uint32_t envCount = S.envLightCount;
+    if (S.lightCount > 0 || envCount > 0) {
+      const float pInfinite = S.lightCount == 0 ? 1.0f : (float)envCount / (float)(envCount + 1);
+      vec3 Li, lpos, lwi;
+      float lpdf, pLight;
+      if (rz < pInfinite) {
+        rz = rz / pInfinite;
+        pLight = pInfinite / (float)envCount;
+        const EnvSample es = sample_environment(S, rl);  // sampleEnvironmentLight, kernel.metal:440-467
+        Li = es.Li; lpos = es.wi * 100.0f; lwi = es.wi; lpdf = es.pdf;
+      } else {
+        rz = (rz - pInfinite) / (1.0f - pInfinite);
+        const pt_area_light light = S.lights[sampleLightPower(S, rz)];
+        pLight = (1.0f - pInfinite) * light.power / S.totalLightPower;
+        // sampleAreaLight (kernel.metal:407-435)
+        const InstanceInfo linst = S.instances[light.instanceIdx];
+        const uint32_t vb = S.meshes[linst.mesh].vertex_base;
+        const vec3 q0 = ld3(S.positions[vb + light.indices[0]]);
+        const vec3 q1 = ld3(S.positions[vb + light.indices[1]]);
+        const vec3 q2 = ld3(S.positions[vb + light.indices[2]]);
+        const vec2 sc = sampleTriUniform(rl);
+        const Xform lx = load_xform(linst);
+        const vec3 osNormal = cross(q1 - q0, q2 - q0);
+        lpos = transformPoint(interpolate3(q0, q1, q2, sc.x, sc.y), lx);
+        const vec3 lnormal = normalize(transformVec(osNormal, lx));
+        lwi = normalize(lpos - hitPos);
+        lpdf = length_squared(lpos - hitPos) / (fabsf(dot(lnormal, lwi)) * light.area);
+        Li = ld3(light.emission);
+      }
 
       const vec3 wi = frame.worldToLocal(lwi);
       const BsdfEval ev = bsdf.eval(wo, wi);
       if (length_squared(ev.f) > 0.0f) {
-        halton.dim++;  // `ir` payload of the shadow ray (kernel.metal:625)
+        // `ir` payload of the shadow ray (kernel.metal:625): only evaluated when an alpha test can consume it
+        out.shadow_payload = S.has_alpha ? halton.sample1d() : (halton.dim++, 0.0f);
         const float pdfLight = pLight * lpdf;
-        const vec3 Ld = ld3(light.emission) * ev.f * fabsf(wi.z) / (pdfLight + ev.pdf);
+        const vec3 Ld = Li * ev.f * fabsf(wi.z) / (pdfLight + ev.pdf);
         out.shadow = true;
         out.shadow_o = hitPos;
         out.shadow_d = lwi;

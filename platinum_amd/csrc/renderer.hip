@@ -94,6 +94,10 @@ struct pt_renderer {
   DevBuf<pt_material_gpu> materials;
   DevBuf<pt_area_light> lights_d;
   std::vector<pt_area_light> lights;
+  DevBuf<vec4> tex_pixels;            // all textures decoded to linear float4 (host_scene.h decode_textures)
+  DevBuf<TexInfo> textures;
+  DevBuf<pt_alias_entry> env_alias_d;
+  std::vector<pt_alias_entry> env_alias;
   LbvhResult bvh{};
   DeviceScene S{};
   pt_render_params params{};
@@ -136,7 +140,7 @@ struct pt_renderer {
 
   void free_scene() {
     positions.release(); vdata.release(); indices.release(); slots.release(); meshes.release(); instances.release();
-    materials.release(); lights_d.release();
+    materials.release(); lights_d.release(); tex_pixels.release(); textures.release(); env_alias_d.release();
     if (bvh.nodes) (void)hipFree(bvh.nodes);
     if (bvh.tris) (void)hipFree(bvh.tris);
     bvh = LbvhResult{};
@@ -389,6 +393,10 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
   PT_HIP(r->instances.upload(hs.instances));
   PT_HIP(r->materials.upload(hs.materials));
   PT_HIP(r->lights_d.upload(r->lights));
+  PT_HIP(r->tex_pixels.upload(hs.tex_pixels));
+  PT_HIP(r->textures.upload(hs.textures));
+  PT_HIP(r->env_alias_d.upload(hs.env_alias));
+  r->env_alias = std::move(hs.env_alias);
 
   DeviceScene& S = r->S;
   memset(&S, 0, sizeof(S));
@@ -399,6 +407,10 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
   S.camera = C.camera;
   S.idt = idt;
   S.width = p->width; S.height = p->height;
+  S.tex_pixels = r->tex_pixels.p; S.textures = r->textures.p; S.env_alias = r->env_alias_d.p;
+  S.env_texture = hs.env_texture;
+  S.envLightCount = C.envLightCount;
+  S.has_alpha = hs.has_alpha ? 1u : 0u;
   S.lightCount = C.lightCount;
   S.totalLightPower = C.totalLightPower;
   S.flags = p->flags;
@@ -637,6 +649,15 @@ int pt_get_lights(const pt_renderer* r, pt_area_light* out, uint32_t capacity, u
   *count = (uint32_t)r->lights.size();
   if (out)
     for (uint32_t i = 0; i < std::min<uint32_t>(capacity, *count); i++) out[i] = r->lights[i];
+  return PT_OK;
+}
+
+int pt_get_env_alias(const pt_renderer* r, pt_alias_entry* out, uint64_t capacity, uint64_t* count) {
+  if (!r || !count) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
+  *count = r->env_alias.size();
+  if (out)
+    for (uint64_t i = 0; i < std::min<uint64_t>(capacity, *count); i++) out[i] = r->env_alias[i];
   return PT_OK;
 }
 

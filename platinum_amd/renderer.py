@@ -150,6 +150,15 @@ class Renderer:
         abi.check(self._lib, self._lib.pt_get_lights(self._h, arr, n.value, C.byref(n)))
         return list(arr)[: n.value]
 
+    def envAlias(self):
+        """The environment alias table in use (Environment::rebuildAliasTable, core/environment.cpp:5-91)."""
+        n = C.c_uint64()
+        abi.check(self._lib, self._lib.pt_get_env_alias(self._h, None, 0, C.byref(n)))
+        arr = np.zeros(n.value, dtype=abi.ALIAS_DTYPE)
+        if n.value:
+            abi.check(self._lib, self._lib.pt_get_env_alias(self._h, arr.ctypes.data, n.value, C.byref(n)))
+        return arr
+
     def tracePrimary(self, sample_idx=0):
         w, h = self.size
         out = np.zeros(w * h, dtype=[("t", "f4"), ("u", "f4"), ("v", "f4"), ("instance", "i4"), ("primitive", "i4")])

@@ -147,10 +147,18 @@ class Material:  # core/material.hpp:15-49 (texture slots are a "next" row)
     clearcoat: float = 0.0
     clearcoat_roughness: float = 0.05
     thin_transmission: bool = False
+    # texture slots (material.hpp:16-23): indices into Scene.textures, -1 = none
+    base_texture: int = -1
+    rm_texture: int = -1
+    transmission_texture: int = -1
+    clearcoat_texture: int = -1
+    emission_texture: int = -1
+    normal_texture: int = -1
+    base_texture_has_alpha: bool = False
 
     def is_emissive(self):  # material.hpp:44-47
         e = np.asarray(self.emission, dtype=f32) * f32(self.emission_strength)
-        return float(np.dot(e, e)) > 0.0
+        return float(np.dot(e, e)) > 0.0 or self.emission_texture >= 0
 
     def to_gpu(self):  # renderer_pt.cpp:583-633
         m = abi.MaterialGPU()
@@ -164,15 +172,15 @@ class Material:  # core/material.hpp:15-49 (texture slots are a "next" row)
         flags = 0
         if self.thin_transmission:
             flags |= abi.MATERIAL_THIN_DIELECTRIC
-        if self.base_color[3] < 1.0:
+        if self.base_color[3] < 1.0 or (self.base_texture >= 0 and self.base_texture_has_alpha):  # renderer_pt.cpp:628-630
             flags |= abi.MATERIAL_USE_ALPHA
         if self.anisotropy != 0.0:
             flags |= abi.MATERIAL_ANISOTROPIC
         if self.is_emissive():
             flags |= abi.MATERIAL_EMISSIVE
         m.flags = flags
-        m.baseTextureId = m.rmTextureId = m.transmissionTextureId = -1
-        m.clearcoatTextureId = m.emissionTextureId = m.normalTextureId = -1
+        m.baseTextureId, m.rmTextureId, m.transmissionTextureId = self.base_texture, self.rm_texture, self.transmission_texture
+        m.clearcoatTextureId, m.emissionTextureId, m.normalTextureId = self.clearcoat_texture, self.emission_texture, self.normal_texture
         return m
 
 
@@ -290,12 +298,31 @@ class Node:
 
 
 @dataclass
+class TextureData:  # core/texture.hpp + loaders/texture.cpp:30-48 (pixel format per TextureType)
+    pixels: np.ndarray  # (H, W, C) uint8 or float32
+    format: int         # abi.TEX_*
+
+
+@dataclass
 class Scene:
     meshes: list = field(default_factory=list)
     nodes: list = field(default_factory=list)
+    textures: list = field(default_factory=list)
+    env_texture: int = -1
+    env_alias: object = None     # optional host-built alias table, numpy array of abi.ALIAS_DTYPE (width*height entries)
     camera: Camera = field(default_factory=Camera)
     camera_world: np.ndarray = field(default_factory=mat_identity)
     name: str = "scene"
+
+    def add_texture(self, pixels, fmt):
+        chans = {abi.TEX_RGBA8_SRGB: 4, abi.TEX_RGBA8: 4, abi.TEX_RG8: 2, abi.TEX_R8: 1, abi.TEX_RGBA32F: 4}[fmt]
+        dt = np.float32 if fmt == abi.TEX_RGBA32F else np.uint8
+        px = np.ascontiguousarray(pixels, dtype=dt)
+        if px.ndim == 2:
+            px = px[..., None]
+        assert px.ndim == 3 and px.shape[2] == chans, (px.shape, chans)
+        self.textures.append(TextureData(px, fmt))
+        return len(self.textures) - 1
 
     def add_mesh(self, mesh):
         self.meshes.append(mesh)
@@ -347,7 +374,22 @@ class Snapshot:
             self._keep.append(mats)
             self.instance_materials[k].materials = C.addressof(mats)
             self.instance_materials[k].material_count = len(n.materials)
+        nt = len(scene.textures)
+        self.textures = (abi.Texture * max(1, nt))()
+        for k, t in enumerate(scene.textures):
+            self._keep.append(t.pixels)
+            self.textures[k].pixels = t.pixels.ctypes.data
+            self.textures[k].height, self.textures[k].width = t.pixels.shape[0], t.pixels.shape[1]
+            self.textures[k].format = t.format
         self.struct = abi.SceneSnapshot()
+        self.struct.textures = C.addressof(self.textures) if nt else None
+        self.struct.texture_count = nt
+        self.struct.env_texture = scene.env_texture
+        self.struct.env_alias = None
+        if scene.env_alias is not None:
+            al = np.ascontiguousarray(scene.env_alias, dtype=abi.ALIAS_DTYPE)
+            self._keep.append(al)
+            self.struct.env_alias = al.ctypes.data
         self.struct.meshes = C.addressof(self.meshes)
         self.struct.mesh_count = nm
         self.struct.instance_count = ni
@@ -435,6 +477,87 @@ def field_scene(grid=32):
         y = 0.25 * s + 3.0 * u[2] * (1 if kind >= 4 else 0)
         sc.add_instance(ball, Transform(translation=(x, y, z), scale=(s, s, s)), [mat])
     sc.set_camera(Camera.with_focal_length(28.0), Transform(translation=(0, 14, 31.5), target=(0, 2, 0), track=True))
+    return sc
+
+
+def _hash_bytes(shape, seed):
+    """Deterministic u8 noise from pcg4d (no numpy RNG: the fixtures must not depend on a library's generator)."""
+    n = int(np.prod(shape))
+    out = np.zeros(n, dtype=np.uint8)
+    for i in range(0, n, 16):
+        h = _pcg4d((i, seed, 0, 0))
+        b = b"".join(int(c).to_bytes(4, "little") for c in h)
+        out[i:i + 16] = np.frombuffer(b, dtype=np.uint8)[: n - i]
+    return out.reshape(shape)
+
+
+def sky_environment(width=32, height=16, sun=(9, 4), sun_radiance=60.0):
+    """A procedural RGBA32F lat-long environment: blue-to-white sky gradient, dim ground, one bright sun texel block."""
+    y = (np.arange(height, dtype=f32) + f32(0.5)) / f32(height)
+    x = (np.arange(width, dtype=f32) + f32(0.5)) / f32(width)
+    t = np.clip((f32(0.5) - y) * f32(2.0), 0, 1).astype(f32)[:, None]
+    px = np.zeros((height, width, 4), dtype=f32)
+    px[..., 0] = f32(0.9) - f32(0.6) * t
+    px[..., 1] = f32(0.9) - f32(0.35) * t
+    px[..., 2] = f32(1.0) - f32(0.05) * t
+    px[..., :3] *= (f32(0.6) + f32(0.4) * np.cos(x * f32(6.2831853))[None, :, None]).astype(f32)
+    px[y > 0.5] *= f32(0.15)
+    sx, sy = sun
+    px[sy:sy + 2, sx:sx + 2, :3] = f32(sun_radiance)
+    px[..., 3] = 1.0
+    return px
+
+
+def textured_scene(env=True, area_light=True, alpha=True):
+    """N3 test scene: every texture slot of core/material.hpp:16-23, a normal map, cut-out (alpha-tested) geometry,
+    an emission-textured area light and (optionally) an importance-sampled environment map."""
+    sc = Scene(name="textured")
+    # --- textures ---
+    chk = np.zeros((16, 16, 4), dtype=np.uint8)
+    yy, xx = np.mgrid[0:16, 0:16]
+    on = ((xx // 4 + yy // 4) % 2).astype(bool)
+    chk[..., 0] = np.where(on, 220, 40); chk[..., 1] = np.where(on, 180, 60); chk[..., 2] = np.where(on, 60, 200); chk[..., 3] = 255
+    chk[..., :3] = (chk[..., :3].astype(np.int32) + (_hash_bytes((16, 16, 3), 1) >> 3)).clip(0, 255).astype(np.uint8)
+    t_base = sc.add_texture(chk, abi.TEX_RGBA8_SRGB)
+    t_rm = sc.add_texture(np.maximum(_hash_bytes((8, 8, 2), 2), 24), abi.TEX_RG8)
+    nrm = np.zeros((16, 16, 4), dtype=np.uint8)
+    nrm[..., 0] = 128 + (np.sin(xx * 0.8) * 50).astype(np.int32)
+    nrm[..., 1] = 128 + (np.cos(yy * 0.6) * 50).astype(np.int32)
+    nrm[..., 2] = 230; nrm[..., 3] = 255
+    t_nrm = sc.add_texture(nrm, abi.TEX_RGBA8)
+    cut = np.zeros((32, 32, 4), dtype=np.uint8)
+    yy2, xx2 = np.mgrid[0:32, 0:32]
+    r2 = (xx2 % 16 - 7.5) ** 2 + (yy2 % 16 - 7.5) ** 2
+    cut[..., 0] = 200; cut[..., 1] = 90; cut[..., 2] = 50
+    cut[..., 3] = np.clip(255 - r2 * 6.0, 0, 255).astype(np.uint8)  # soft holes: exercises the stochastic test
+    t_cut = sc.add_texture(cut, abi.TEX_RGBA8_SRGB)
+    t_tr = sc.add_texture(_hash_bytes((8, 8), 3), abi.TEX_R8)
+    t_cc = sc.add_texture(_hash_bytes((4, 4), 4), abi.TEX_R8)
+    em = np.zeros((4, 4, 4), dtype=np.uint8)
+    em[..., :3] = 64 + (_hash_bytes((4, 4, 3), 5) // 2); em[..., 3] = 255
+    t_em = sc.add_texture(em, abi.TEX_RGBA8_SRGB)
+    # --- geometry ---
+    quad = sc.add_mesh(plane(1.0))
+    ball = sc.add_mesh(sphere(1.0, 16, 24))
+    sc.add_instance(quad, Transform(scale=(12, 1, 12)),
+                    [Material(name="floor", base_texture=t_base, rm_texture=t_rm, normal_texture=t_nrm, roughness=0.9, metallic=0.6)])
+    if alpha:
+        sc.add_instance(quad, Transform(translation=(-1.0, 2.0, 1.5), rotation=(np.pi / 2, 0, 0), scale=(4, 1, 4)),
+                        [Material(name="cutout", base_texture=t_cut, base_texture_has_alpha=True, roughness=0.6)])
+        sc.add_instance(ball, Transform(translation=(2.6, 0.8, 2.0), scale=(0.8, 0.8, 0.8)),
+                        [Material(name="ghost", base_color=(0.2, 0.8, 0.3, 0.5), roughness=0.4)])
+    sc.add_instance(ball, Transform(translation=(-0.5, 1.3, -1.0), scale=(1.3, 1.3, 1.3)),
+                    [Material(name="frosted", base_color=(1, 1, 1, 1), roughness=0.25, ior=1.45, transmission=1.0,
+                              transmission_texture=t_tr, clearcoat=1.0, clearcoat_texture=t_cc, rm_texture=t_rm)])
+    sc.add_instance(ball, Transform(translation=(2.4, 1.0, -1.5)),
+                    [Material(name="bumpy metal", base_texture=t_base, normal_texture=t_nrm, roughness=0.35, metallic=1.0)])
+    if area_light:
+        sc.add_instance(quad, Transform(translation=(0, 5.5, 0), rotation=(np.pi, 0, 0), scale=(3, 1, 3)),
+                        [Material(name="panel", base_color=(0, 0, 0, 1), emission=(1.0, 0.9, 0.8), emission_strength=6.0,
+                                  emission_texture=t_em)])
+    if env:
+        sc.env_texture = sc.add_texture(sky_environment(), abi.TEX_RGBA32F)
+    sc.set_camera(Camera.with_focal_length(28.0), Transform(translation=(0.5, 3.0, 8.0), target=(0, 1.2, 0), track=True))
     return sc
 
 

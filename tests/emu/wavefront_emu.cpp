@@ -132,6 +132,8 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
   S.camera = e->hs.constants.camera; S.idt = e->hs.idt; S.width = p->width; S.height = p->height;
   S.lightCount = e->hs.constants.lightCount; S.totalLightPower = e->hs.constants.totalLightPower;
   S.flags = p->flags; S.integrator = p->integrator; S.max_bounces = p->max_bounces;
+  S.tex_pixels = e->hs.tex_pixels.data(); S.textures = e->hs.textures.data(); S.env_alias = e->hs.env_alias.data();
+  S.env_texture = e->hs.env_texture; S.envLightCount = e->hs.constants.envLightCount; S.has_alpha = e->hs.has_alpha ? 1u : 0u;
   return e;
 }
 void emu_destroy(void* h) { delete (Emu*)h; }
@@ -158,15 +160,19 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
       for (uint32_t b = 0; b < B; b++) {
         TraversalStack st; st.lds = lds.data(); st.lds_stride = 1; st.spill = spill.data(); st.spill_stride = 1;
         TraversalCount tc;
-        RayHit hit = traverse<false, false>(S, o, d, 1e-3f, kInf, st, &tc);
+        const float ir = S.has_alpha ? Halton{S.halton, rg.offset, dim}.sample1d() : 0.0f;
+        RayHit hit = traverse<false, false>(S, o, d, 1e-3f, kInf, ir, st, &tc);
         if (hits && hit.tri != kInvalidRef) { hits[((size_t)b * NP + pid) * 2] = S.tris[hit.tri].inst; hits[((size_t)b * NP + pid) * 2 + 1] = S.tris[hit.tri].prim; }
-        if (hit.tri == kInvalidRef) break;
+        if (hit.tri == kInvalidRef) {
+          if (S.env_texture >= 0) L = L + stage_miss(S, d, att, b, lastPdf, lastSpec);
+          break;
+        }
         ShadeIn in; in.o = o; in.d = d; in.att = att; in.lastPdf = lastPdf; in.lastSpecular = lastSpec; in.offset = rg.offset;
         in.dim = dim + 1; in.bounce = b; in.t = hit.t; in.u = hit.u; in.v = hit.v; in.tri = hit.tri;
         ShadeOut out = stage_shade(S, in);
         if (out.has_emitted) L = L + out.emitted;
         if (out.shadow) {
-          RayHit sh = traverse<true, false>(S, out.shadow_o, out.shadow_d, 1e-3f, out.shadow_tmax, st, &tc);
+          RayHit sh = traverse<true, false>(S, out.shadow_o, out.shadow_d, 1e-3f, out.shadow_tmax, out.shadow_payload, st, &tc);
           if (sh.tri == kInvalidRef) L = L + out.shadow_contrib;
         }
         if (!out.alive) break;
@@ -186,7 +192,8 @@ void emu_trace_primary(void* h, uint32_t sample, pt_hit_record* out) {
       RayGenOut rg = stage_raygen(S, x, y, sample);
       TraversalStack st; st.lds = lds.data(); st.lds_stride = 1; st.spill = spill.data(); st.spill_stride = 1;
       TraversalCount tc;
-      RayHit hit = traverse<false, false>(S, rg.o, rg.d, 1e-3f, kInf, st, &tc);
+      const float ir = S.has_alpha ? Halton{S.halton, rg.offset, rg.dim}.sample1d() : 0.0f;
+      RayHit hit = traverse<false, false>(S, rg.o, rg.d, 1e-3f, kInf, ir, st, &tc);
       pt_hit_record& r = out[y * S.width + x];
       if (hit.tri != kInvalidRef) { r.t = hit.t; r.u = hit.u; r.v = hit.v; r.instance = S.tris[hit.tri].inst; r.primitive = S.tris[hit.tri].prim; }
       else { r.t = r.u = r.v = 0; r.instance = r.primitive = -1; }

@@ -45,6 +45,12 @@ def lib():
     L.orc_scene_destroy.argtypes = [C.c_void_p]
     L.orc_get_constants.argtypes = [C.c_void_p, C.POINTER(abi.Constants)]
     L.orc_get_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.orc_atan2.restype = C.c_float; L.orc_atan2.argtypes = [C.c_float, C.c_float]
+    L.orc_acos.restype = C.c_float; L.orc_acos.argtypes = [C.c_float]
+    L.orc_tex_sample.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    L.orc_ray_dir_to_uv.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_uv_to_ray_dir.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_get_env_alias.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int]
     L.orc_gmon_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]
     L.orc_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.PostOptions), C.POINTER(abi.TonemapOptions), C.c_void_p, C.c_void_p]
@@ -114,6 +120,19 @@ class OracleScene:
         arr = (abi.AreaLight * max(1, n.value))()
         self.L.orc_get_lights(self.h, arr, n.value, C.byref(n))
         return list(arr)[: n.value]
+
+    def tex_sample(self, texture, u, v):
+        out = np.zeros(4, dtype=np.float32)
+        self.L.orc_tex_sample(self.h, texture, u, v, out.ctypes.data)
+        return out
+
+    def envAlias(self):
+        n = C.c_uint64()
+        self.L.orc_get_env_alias(self.h, None, 0, C.byref(n))
+        arr = np.zeros(n.value, dtype=abi.ALIAS_DTYPE)
+        if n.value:
+            self.L.orc_get_env_alias(self.h, arr.ctypes.data, n.value, C.byref(n))
+        return arr
 
     def render(self, first_sample, nsamples, acc=None, acc_n0=0, threads=None, count_traversal=False):
         if acc is None:

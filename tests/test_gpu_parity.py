@@ -219,3 +219,100 @@ def test_postprocess_tonemap_rgba8_matches_oracle(gpu_renderer):
         assert g[..., :3].std() > 5
     gpu_renderer.setPostProcessOptions(gpu_renderer.postProcessOptions())
     gpu_renderer.setTonemapOptions(gpu_renderer.tonemapOptions())
+
+
+# ---- textures, normal maps, alpha-tested cut-outs, environment light ------------------------------
+N3_VARIANTS = {
+    "full": dict(),
+    "env_only": dict(area_light=False),     # lightCount == 0: pInfinite = 1
+    "no_env": dict(env=False),
+    "opaque": dict(alpha=False),            # has_alpha == 0: the payload is never evaluated
+}
+
+
+@pytest.mark.parametrize("variant,integrator", [("full", abi.INTEGRATOR_MIS), ("full", abi.INTEGRATOR_SIMPLE),
+                                                ("env_only", abi.INTEGRATOR_MIS), ("no_env", abi.INTEGRATOR_MIS),
+                                                ("opaque", abi.INTEGRATOR_MIS)])
+def test_textured_scene_hit_ids_and_radiance(gpu_renderer, variant, integrator):
+    sc = scenes.textured_scene(**N3_VARIANTS[variant])
+    w, h = 200, 112
+    p = _start(gpu_renderer, sc, w, h, 4, 7, integrator=integrator)
+    o = oracle_lib.OracleScene(sc, p)
+    assert bytes(gpu_renderer.constants()) == bytes(o.constants())
+    lg, lo = gpu_renderer.lights(), o.lights()
+    assert len(lg) == len(lo) and all(bytes(a) == bytes(b) for a, b in zip(lg, lo))
+    ag, ao = gpu_renderer.envAlias(), o.envAlias()
+    assert ag.tobytes() == ao.tobytes() and (len(ag) > 0) == (variant != "no_env")
+    for s in (0, 3):
+        g, c = gpu_renderer.tracePrimary(s), o.trace_primary(s)
+        assert g.tobytes() == c.tobytes()
+        rg, hg = gpu_renderer.debugSample(s)
+        rc, hc = o.debug_sample(s)
+        assert np.array_equal(hg, hc), f"hit ids differ at {np.argwhere((hg != hc).any(-1))[:5]}"
+        np.testing.assert_allclose(rg, rc, rtol=REL_TOL, atol=1e-7)
+        assert rg.tobytes() == rc.tobytes()
+    assert rc[..., :3].mean() > 1e-3
+
+
+def test_textured_scene_accumulator_and_golden(gpu_renderer):
+    """The N3 golden fixture (tests/golden/n3_textured_golden.npz, minted from the oracle) through the product path."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "n3_textured_golden.npz"))
+    sc = scenes.textured_scene()
+    _start(gpu_renderer, sc, 96, 54, 2, 6)
+    gpu_renderer.render(0)
+    acc = gpu_renderer.readbackAccumulator()
+    assert acc.tobytes() == g["acc2"].tobytes()
+    _, hits = gpu_renderer.debugSample(0)
+    assert np.array_equal(hits.astype(np.int16), g["hits0"])
+    # multi-batch accumulation (samples_in_flight 1) reproduces the same bits
+    _start(gpu_renderer, sc, 96, 54, 2, 6, samples_in_flight=1)
+    gpu_renderer.render(0)
+    assert gpu_renderer.readbackAccumulator().tobytes() == g["acc2"].tobytes()
+
+
+def test_host_supplied_alias_table_is_used_verbatim(gpu_renderer):
+    sc = scenes.textured_scene(area_light=False)
+    p = make_params(64, 36, 1, 4)
+    o = oracle_lib.OracleScene(sc, p)
+    al = o.envAlias().copy()
+    al["p"] = 1.0            # a (wrong but legal) table: never redirect => uniform texel sampling with the luma pdf
+    sc.env_alias = al
+    _start(gpu_renderer, sc, 64, 36, 1, 4)
+    assert gpu_renderer.envAlias().tobytes() == al.tobytes()
+    o2 = oracle_lib.OracleScene(sc, p)
+    rg, hg = gpu_renderer.debugSample(0)
+    rc, hc = o2.debug_sample(0)
+    assert np.array_equal(hg, hc) and rg.tobytes() == rc.tobytes()
+    r0, _ = o.debug_sample(0)
+    assert r0.tobytes() != rc.tobytes()  # and it matters
+
+
+def test_texture_argument_validation(gpu_renderer):
+    sc = scenes.textured_scene(env=False)
+    sc.nodes[0].materials[0].base_texture = 99
+    with pytest.raises(abi.PtamdError, match="texture id out of range"):
+        _start(gpu_renderer, sc, 32, 18, 1, 2)
+    sc = scenes.textured_scene(env=False)
+    sc.env_texture = 42
+    with pytest.raises(abi.PtamdError, match="env_texture out of range"):
+        _start(gpu_renderer, sc, 32, 18, 1, 2)
+
+
+def test_textured_scene_large_image_properties(gpu_renderer):
+    """1920x1080, 8 spp, textures + cut-outs + environment: finite accumulator, alpha = 1, and the accumulator of a
+    two-way sample split merges to the same running mean within fp32 reassociation."""
+    sc = scenes.textured_scene()
+    _start(gpu_renderer, sc, 1920, 1080, 8, 6, nonfinite_policy=abi.NONFINITE_ZERO)
+    gpu_renderer.render(0)
+    acc = gpu_renderer.readbackAccumulator()
+    assert np.isfinite(acc).all() and np.all(acc[..., 3] == 1.0)
+    st = gpu_renderer.stats()
+    assert st.paths == 1920 * 1080 * 8 and st.shadow_rays > 0
+    halves = []
+    for first in (0, 4):
+        _start(gpu_renderer, sc, 1920, 1080, 4, 6, first_sample=first, nonfinite_policy=abi.NONFINITE_ZERO)
+        gpu_renderer.render(0)
+        halves.append(gpu_renderer.readbackAccumulator())
+    merged = 0.5 * (halves[0][..., :3].astype(np.float64) + halves[1][..., :3])
+    np.testing.assert_allclose(acc[..., :3], merged, rtol=2e-5, atol=1e-6)

@@ -10,6 +10,8 @@ as small fixtures under tests/golden/.  Re-running must reproduce the files bit-
                           per-channel means and a sha256 of the full images; primary-ray (instance, primitive) map
                           checksum and a 64x64 crop of (t,u,v)
   c2_small_golden.npz     Cornell + glass sphere, 160x90, 8 bounces: full accumulator at 2 spp + per-bounce hit ids of sample 0
+  n3_textured_golden.npz  scenes.textured_scene() (textures, normal map, cut-outs, environment), 96x54, 6 bounces: accumulator
+                          at 2 spp, per-bounce hit ids of sample 0, the environment alias table
 """
 import hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -52,5 +54,12 @@ o2 = oracle_lib.OracleScene(sc2, make_params(160, 90, 2, 8))
 acc2 = o2.render(0, 2)
 rad0, hits0 = o2.debug_sample(0)
 np.savez_compressed(os.path.join(G, "c2_small_golden.npz"), acc2=acc2, hits0=hits0.astype(np.int16), rad0=rad0)
+# ---- N3 textured scene ----
+o3 = oracle_lib.OracleScene(scenes.textured_scene(), make_params(96, 54, 2, 6))
+acc3 = o3.render(0, 2)
+rad3, hits3 = o3.debug_sample(0)
+al = o3.envAlias()
+np.savez_compressed(os.path.join(G, "n3_textured_golden.npz"), acc2=acc3, hits0=hits3.astype(np.int16),
+                    alias_pdf=al["pdf"], alias_p=al["p"], alias_idx=al["aliasIdx"])
 for f in sorted(os.listdir(G)):
     print(f, os.path.getsize(os.path.join(G, f)))
