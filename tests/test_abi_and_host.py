@@ -23,6 +23,13 @@ def test_library_exports_every_declared_symbol():
     assert declared == {name for name, _, _ in abi.SYMBOLS}
     for name in declared:
         assert hasattr(lib, name)
+    # include/ptamd_scene.h (scene ingestion)
+    from platinum_amd import scene_io
+    hdr2 = open(os.path.join(ROOT, "include", "ptamd_scene.h")).read()
+    declared2 = set(re.findall(r"\b(pt_[a-z_]+)\s*\(", hdr2))
+    assert declared2 == {name for name, _, _ in scene_io.SCENE_SYMBOLS}
+    for name in declared2:
+        assert hasattr(lib, name)
 
 
 def test_struct_layouts_match_reference_abi():

@@ -1,0 +1,475 @@
+"""CPU: SURVEY §8f row N4 — scene ingestion (include/ptamd_scene.h; platinum_amd/csrc/scene_io.cpp, scene_gltf.cpp).
+
+  * the reference's scene.json + _data.bin (core/scene.cpp:30-84, 536-903): files are written here by an independent
+    Python restatement of Scene::saveToFile (tests/scene_formats.py) and by the committed fixture
+    tests/golden/scene_fixture/mini.{json,_data.bin}; the C++ reader's snapshot is compared field by field with what
+    rebuildResourceBuffers / getInstances would hand the renderer (index assignment in asset order, LIFO traversal, pruned
+    invisible subtrees, default materials, per-instance MaterialGPU flags, camera world transform, environment)
+  * MikkTSpace tangents against the reference's own deps/mikkt/mikktspace.c (oracle/_ref/libmikkt.so), bit-exact, and
+    against the committed fixture tests/golden/mikkt_tangents.npz minted from it
+  * the glTF importer (loaders/gltf.cpp): accessors, interleaving, normalized integers, .gltf/.glb/data URIs, TRS and matrix
+    nodes (fastgltf decomposition + the reference's eulerFromQuat), cameras, KHR material extensions, PNG textures
+    converted per TextureType, tangent generation when the file has none
+The loaded scenes render through the oracle here and through the HIP path in test_gpu_parity.py."""
+import ctypes as C
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import scene_formats as sf
+from platinum_amd import abi, scene_io, scenes
+from platinum_amd.renderer import make_params
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+f32 = np.float32
+
+
+# ---- helpers: read a pt_scene_snapshot back into numpy --------------------------------------------------------------
+def snap_meshes(s):
+    arr = C.cast(s.meshes, C.POINTER(abi.Mesh))
+    out = []
+    for i in range(s.mesh_count):
+        m = arr[i]
+        pos = np.ctypeslib.as_array(C.cast(m.positions, C.POINTER(C.c_float)), (m.vertex_count, 4)).copy()
+        vd = np.ctypeslib.as_array(C.cast(m.vertex_data, C.POINTER(C.c_float)), (m.vertex_count, 12)).copy()
+        idx = np.ctypeslib.as_array(C.cast(m.indices, C.POINTER(C.c_uint32)), (3 * m.triangle_count,)).copy()
+        sl = np.ctypeslib.as_array(C.cast(m.material_slots, C.POINTER(C.c_uint32)), (m.triangle_count,)).copy()
+        out.append((pos, vd, idx, sl))
+    return out
+
+
+def snap_instances(s):
+    inst = C.cast(s.instances, C.POINTER(abi.Instance))
+    mats = C.cast(s.instance_materials, C.POINTER(abi.InstanceMaterials))
+    out = []
+    for i in range(s.instance_count):
+        tr = np.array([[inst[i].transform[c][r] for r in range(3)] for c in range(4)], dtype=f32)
+        ml = C.cast(mats[i].materials, C.POINTER(abi.MaterialGPU))
+        out.append((inst[i].accelerationStructureIndex, tr, [ml[k] for k in range(mats[i].material_count)], inst[i].mask))
+    return out
+
+
+def snap_textures(s):
+    tex = C.cast(s.textures, C.POINTER(abi.Texture))
+    bpp = {abi.TEX_RGBA8_SRGB: 4, abi.TEX_RGBA8: 4, abi.TEX_RG8: 2, abi.TEX_R8: 1, abi.TEX_RGBA32F: 16}
+    out = []
+    for i in range(s.texture_count):
+        n = tex[i].width * tex[i].height * bpp[tex[i].format]
+        out.append((tex[i].width, tex[i].height, tex[i].format, C.string_at(tex[i].pixels, n)))
+    return out
+
+
+def world(*chain):
+    """Product of Transform matrices down a hierarchy, root first (core/scene.cpp:524)."""
+    m = scenes.mat_identity()
+    for t in chain:
+        m = scenes.mat_mul(m, t.matrix())
+    return m
+
+
+# ---- the "mini" scene of the committed fixture ----------------------------------------------------------------------
+def mini_scene_spec():
+    rng = np.random.default_rng(17)
+    base = rng.integers(0, 256, (8, 8, 4), dtype=np.uint8)
+    base[..., 3] = np.where(np.arange(8)[None, :] < 4, 255, 90)
+    rm = rng.integers(16, 256, (4, 4, 2), dtype=np.uint8)
+    env = scenes.sky_environment(16, 8, sun=(5, 2), sun_radiance=40.0)
+    plane, ball = scenes.plane(1.0), scenes.sphere(0.5, 6, 8)
+    # alias table: what the reference stores is Environment's own table; take the library-independent oracle's
+    tmp = scenes.Scene()
+    tmp.add_instance(tmp.add_mesh(plane), scenes.Transform(), [scenes.Material()])
+    tmp.env_texture = tmp.add_texture(env, abi.TEX_RGBA32F)
+    alias = oracle_lib.OracleScene(tmp, make_params(8, 8, 1, 1)).envAlias()
+    assets = [
+        {"id": 0, "type": "texture", "name": "base", "alpha": True, "format": "srgb8", "pixels": base, "rc": 1},
+        {"id": 2, "type": "material", "rc": 1, "data": sf.material_json("textured", (1, 1, 1, 1), roughness=0.7, metallic=0.2,
+                                                                         textures=[("base", 0), ("rm", 1)])},
+        {"id": 4, "type": "mesh", "mesh": plane, "rc": 3},
+        {"id": 1, "type": "texture", "name": "rm", "alpha": False, "format": "rg8", "pixels": rm, "rc": 1},
+        {"id": 3, "type": "material", "rc": 1, "data": sf.material_json("lamp", (0, 0, 0, 1), emission=(1, 0.8, 0.6), emission_strength=9.0)},
+        {"id": 5, "type": "mesh", "mesh": ball, "rc": 3, "retain": False},
+        {"id": 6, "type": "material", "rc": 1, "data": sf.material_json("glass", (1, 1, 1, 1), roughness=0.1, transmission=1.0, ior=1.45,
+                                                                         aniso=0.3, thin=True)},
+        {"id": 7, "type": "texture", "name": "sky", "alpha": False, "format": "rgba32f", "pixels": env, "rc": 1},
+    ]
+    T = sf.transform_json
+    root = sf.node_json(0, "Scene", children=[
+        sf.node_json(1, "floor", T(s=(8, 1, 8)), mesh=4, materials=[2]),
+        sf.node_json(2, "group", T(t=(1, 0.5, 0), r=(0.1, 0.7, -0.2), s=(1.5, 1.5, 1.5)), children=[
+            sf.node_json(3, "ball", T(t=(0, 1, 0)), mesh=5, materials=[6]),
+            sf.node_json(4, "hidden", T(t=(0, 2, 0)), visible=False, mesh=5, materials=[6], children=[
+                sf.node_json(5, "hidden child", T(), mesh=4, materials=[2])]),
+            sf.node_json(6, "lamp", T(t=(0, 4, 0), r=(np.pi, 0, 0), s=(2, 1, 2)), mesh=4, materials=[3]),
+        ]),
+        sf.node_json(7, "cam rig", T(t=(0, 1, 0)), children=[
+            sf.node_json(8, "Camera", T(t=(0, 2, 9), tgt=(0, 1, 0), track=True), camera={"f": 35.0, "aperture": 0.0, "sensor": (36.0, 24.0)})]),
+        sf.node_json(9, "plain ball", T(t=(-2, 0.5, 1)), mesh=5, materials=[None]),
+    ])
+    return assets, root, {"texture": 7, "alias": alias}, dict(base=base, rm=rm, env=env, plane=plane, ball=ball, alias=alias)
+
+
+@pytest.fixture(scope="module")
+def mini(tmp_path_factory):
+    d = tmp_path_factory.mktemp("mini")
+    assets, root, envmap, data = mini_scene_spec()
+    path = str(d / "mini.json")
+    sf.write_reference_scene(path, assets, root, envmap)
+    return path, data
+
+
+def check_mini_snapshot(sc, data):
+    Tr = scenes.Transform
+    c = sc.counts()
+    assert (c.nodes, c.meshes, c.textures, c.materials, c.cameras, c.instances) == (10, 2, 3, 3, 1, 4)
+    assert c.triangles == 2 + 2 + 2 * 6 * 8 * 2
+    assert sc.cameras() == [(8, "Camera")]
+    s = sc.snapshot().struct
+    # meshes and textures are indexed in asset (file) order per type (renderer_pt.cpp:485, 525)
+    meshes = snap_meshes(s)
+    for got, want in zip(meshes, (data["plane"], data["ball"])):
+        assert got[0].tobytes() == np.asarray(want.positions, f32).tobytes() and got[1].tobytes() == np.asarray(want.vertex_data, f32).tobytes()
+        assert np.array_equal(got[2], want.indices) and np.array_equal(got[3], want.material_slots)
+    tex = snap_textures(s)
+    assert [(t[0], t[1], t[2]) for t in tex] == [(8, 8, abi.TEX_RGBA8_SRGB), (4, 4, abi.TEX_RG8), (16, 8, abi.TEX_RGBA32F)]
+    assert tex[0][3] == data["base"].tobytes() and tex[1][3] == data["rm"].tobytes() and tex[2][3] == data["env"].tobytes()
+    assert s.env_texture == 2
+    al = np.ctypeslib.as_array(C.cast(s.env_alias, C.POINTER(C.c_uint8)), (16 * 8 * 12,)).tobytes()
+    assert al == data["alias"].tobytes()
+    # instances: LIFO traversal (core/scene.cpp:514-534) => last child first; the invisible node prunes its subtree
+    inst = snap_instances(s)
+    group = Tr(translation=(1, 0.5, 0), rotation=(0.1, 0.7, -0.2), scale=(1.5, 1.5, 1.5))
+    expect = [
+        (1, world(Tr(), Tr(translation=(-2, 0.5, 1)))),
+        (0, world(Tr(), group, Tr(translation=(0, 4, 0), rotation=(np.pi, 0, 0), scale=(2, 1, 2)))),
+        (1, world(Tr(), group, Tr(translation=(0, 1, 0)))),
+        (0, world(Tr(), Tr(scale=(8, 1, 8)))),
+    ]
+    assert [i[0] for i in inst] == [e[0] for e in expect]
+    for (mi, tr, mats, mask), (_, w) in zip(inst, expect):
+        np.testing.assert_allclose(tr, w[:, :3], rtol=2e-6, atol=2e-6)
+        assert mask == 0xFF
+    # materials: per-instance MaterialGPU arrays (renderer_pt.cpp:560-640)
+    default = bytes(scenes.Material().to_gpu())
+    got_default = inst[0][2][0]
+    assert bytes(got_default)[:68] == default[:68] and got_default.flags == 0 and got_default.baseTextureId == -1
+    lamp = inst[1][2][0]
+    assert lamp.flags == abi.MATERIAL_EMISSIVE and lamp.emissionStrength == 9.0 and tuple(lamp.baseColor) == (0, 0, 0, 1)
+    glass = inst[2][2][0]
+    assert glass.flags == abi.MATERIAL_THIN_DIELECTRIC | abi.MATERIAL_ANISOTROPIC and glass.transmission == 1.0 and glass.ior == f32(1.45)
+    floor = inst[3][2][0]
+    assert (floor.baseTextureId, floor.rmTextureId, floor.normalTextureId, floor.emissionTextureId) == (0, 1, -1, -1)
+    assert floor.flags == abi.MATERIAL_USE_ALPHA  # the base texture has alpha (renderer_pt.cpp:628-630)
+    assert floor.roughness == f32(0.7) and floor.metallic == f32(0.2)
+    # camera: world transform up the parent chain (core/scene.cpp:463-474) + Camera::withFocalLength defaults
+    cw = np.array([[s.camera.world[c_][r] for r in range(4)] for c_ in range(4)], dtype=f32)
+    np.testing.assert_allclose(cw, world(Tr(), Tr(translation=(0, 1, 0)), Tr(translation=(0, 2, 9), target=(0, 1, 0), track=True)), rtol=2e-6, atol=2e-6)
+    assert (s.camera.focal_length, s.camera.aperture, s.camera.aperture_blades, s.camera.roundness, s.camera.focus_distance) == (35.0, 0.0, 7, 1.0, 1.0)
+    assert tuple(s.camera.sensor_size) == (36.0, 24.0)
+    return s
+
+
+def test_reference_scene_json_reader(mini):
+    path, data = mini
+    sc = scene_io.SceneFile.load(path)
+    check_mini_snapshot(sc, data)
+
+
+def test_committed_scene_fixture_matches_the_writer(mini, tmp_path):
+    """tests/golden/scene_fixture/mini.json + mini_data.bin (tools/make_golden.py): the reader on committed bytes."""
+    path, data = mini
+    gj, gb = os.path.join(G, "scene_fixture", "mini.json"), os.path.join(G, "scene_fixture", "mini_data.bin")
+    assert open(gb, "rb").read() == open(path.replace(".json", "_data.bin"), "rb").read()
+    assert json.load(open(gj)) == json.load(open(path))
+    check_mini_snapshot(scene_io.SceneFile.load(gj), data)
+
+
+def test_scene_json_save_round_trip(mini, tmp_path):
+    """Scene::saveToFile restated in C++ (pt_scene_save_json): load -> save -> load reproduces the snapshot bytes, and the
+    written json has the reference's structure (same keys, [offset, length] pairs that tile the .bin)."""
+    path, data = mini
+    a = scene_io.SceneFile.load(path)
+    out = str(tmp_path / "again.json")
+    a.save(out)
+    b = scene_io.SceneFile.load(out)
+    check_mini_snapshot(b, data)
+    ja, jb = json.load(open(path)), json.load(open(out))
+    strip_rc = lambda j: [{k: v for k, v in x.items() if k != "rc"} for x in j["assets"]["assets"]]
+    assert strip_rc(ja) == strip_rc(jb) and ja["root"] == jb["root"] and ja["envmap"] == jb["envmap"]
+    # the node pass retains assets again on load (core/scene.cpp:880 -> setMesh -> retainAsset): rc grows exactly like the reference's
+    rc = {x["id"]: x["rc"] for x in jb["assets"]["assets"]}
+    assert rc[4] == 3 + 3 and rc[5] == 3 + 3 and rc[2] == 1 + 2 and rc[0] == 1
+    assert open(out.replace(".json", "_data.bin"), "rb").read() == open(path.replace(".json", "_data.bin"), "rb").read()
+
+
+def test_loaded_scene_renders_through_the_oracle(mini):
+    path, _ = mini
+    sc = scene_io.SceneFile.load(path)
+    p = make_params(64, 36, 1, 5)
+    o = oracle_lib.OracleScene(sc, p)
+    rad, hits = o.debug_sample(0)
+    assert np.isfinite(rad).all() and rad[..., :3].mean() > 1e-3
+    assert set(np.unique(hits[0, ..., 0])) >= {0, 2, 3}  # plain ball, glass ball and floor are in view (the lamp is above the frame)
+    assert (hits[1:, ..., 0] == 1).any()                  # ... and the lamp is reached by secondary rays
+    assert o.constants().envLightCount == 1 and len(o.lights()) == 2
+
+
+def test_scene_reader_errors(tmp_path, mini):
+    path, _ = mini
+    with pytest.raises(abi.PtamdError, match="cannot open"):
+        scene_io.SceneFile.load(str(tmp_path / "missing.json"))
+    d = tmp_path / "trunc"
+    d.mkdir()
+    shutil.copy(path, d / "mini.json")
+    blob = open(path.replace(".json", "_data.bin"), "rb").read()
+    open(d / "mini_data.bin", "wb").write(blob[: len(blob) // 2])
+    with pytest.raises(abi.PtamdError, match="shorter than the json says"):
+        scene_io.SceneFile.load(str(d / "mini.json"))
+    open(d / "bad.json", "w").write('{"assets": {"nextId": 0, "assets": []}, "root": {"id": 0, "name": "x"')
+    open(d / "bad_data.bin", "wb").write(b"")
+    with pytest.raises(abi.PtamdError, match="json:"):
+        scene_io.SceneFile.load(str(d / "bad.json"))
+    sc = scene_io.SceneFile.load(path)
+    sc.camera = 3  # not a camera node
+    with pytest.raises(abi.PtamdError, match="not a camera node"):
+        sc.snapshot()
+
+
+# ---- tangents ----------------------------------------------------------------------------------------------------------
+def tangent_cases():
+    rng = np.random.default_rng(3)
+    n = 9
+    xs, zs = np.meshgrid(np.arange(n), np.arange(n))
+    P = np.stack([xs.ravel(), rng.normal(0, 0.2, n * n), zs.ravel()], -1).astype(f32)
+    N = rng.normal(size=(n * n, 3))
+    N[:, 1] += 3
+    N /= np.linalg.norm(N, axis=1, keepdims=True)
+    UV = np.stack([np.abs(xs.ravel() / (n - 1) - 0.5) * 2, zs.ravel() / (n - 1)], -1).astype(f32)  # mirrored in u: two orientations
+    idx = []
+    for z in range(n - 1):
+        for x in range(n - 1):
+            a = z * n + x
+            idx += [a, a + n, a + 1, a + 1, a + n, a + n + 1]
+    idx += [0, 0, 5, 3, 4, 4]      # degenerate triangles (repeated vertex)
+    UV[40] = UV[41]                # zero-area uv triangles: GROUP_WITH_ANY
+    grid = scenes._make_mesh(P, N, np.zeros((n * n, 4)), UV, idx, np.zeros(len(idx) // 3))
+    return {"plane": scenes.plane(2.0), "cube": scenes.cube(2.0), "sphere": scenes.sphere(1.0, 12, 16), "cornell": scenes.cornell_box(),
+            "grid": grid}
+
+
+@pytest.mark.parametrize("name", ["plane", "cube", "sphere", "cornell", "grid"])
+def test_tangents_match_reference_mikktspace_and_fixture(name):
+    m = tangent_cases()[name]
+    vd = np.ascontiguousarray(m.vertex_data, dtype=f32).copy()
+    vd[:, 4:8] = 0
+    mine = scene_io.generate_tangents(m.positions, vd.copy(), m.indices)[:, 4:8]
+    g = np.load(os.path.join(G, "mikkt_tangents.npz"))
+    assert mine.tobytes() == g[name].tobytes()             # committed output of the reference's mikktspace.c
+    if sf.mikkt_available():                                # and the library itself, where oracle/_ref was built
+        ref = sf.mikkt_reference_tangents(m.positions, vd, m.indices)
+        assert ref.tobytes() == mine.tobytes()
+    assert np.allclose(np.linalg.norm(mine[:, :3], axis=1), 1.0, atol=1e-5) and set(np.unique(mine[:, 3])) <= {-1.0, 1.0}
+
+
+# ---- PNG -----------------------------------------------------------------------------------------------------------------
+def test_png_decoder_all_colour_types(tmp_path):
+    """Through the importer: a glTF whose base-colour texture is the PNG under test (sRGB type = RGBA8 bytes verbatim)."""
+    rng = np.random.default_rng(2)
+    rgba = rng.integers(0, 256, (13, 7, 4), dtype=np.uint8)
+    rgb, grey, ga = rgba[..., :3], rgba[..., 0], rgba[..., [0, 3]]
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    pidx = rng.integers(0, 16, (13, 7), dtype=np.uint8)
+    trns = bytes(rng.integers(0, 256, 10, dtype=np.uint8))
+    rgba16 = rng.integers(0, 65536, (5, 9, 4), dtype=np.uint16)
+    cases = {
+        "rgba": (sf.png_bytes(rgba), rgba),
+        "rgb": (sf.png_bytes(rgb), np.concatenate([rgb, np.full((13, 7, 1), 255, np.uint8)], -1)),
+        "grey": (sf.png_bytes(grey), np.stack([grey, grey, grey, np.full_like(grey, 255)], -1)),
+        "grey_alpha": (sf.png_bytes(ga), np.stack([ga[..., 0]] * 3 + [ga[..., 1]], -1)),
+        "palette_trns": (sf.png_bytes(pidx, palette=pal, trns=trns),
+                         np.concatenate([pal[pidx], np.array([trns[i] if i < 10 else 255 for i in pidx.ravel()], np.uint8).reshape(13, 7, 1)], -1)),
+        "rgba16": (sf.png_bytes(rgba16), (rgba16 >> 8).astype(np.uint8)),
+        "filter_paeth_only": (sf.png_bytes(rgba, filter_type=4), rgba),
+    }
+    for name, (png, want) in cases.items():
+        b = sf.GltfBuilder()
+        t = b.image_png(png)
+        b.doc["materials"].append({"pbrMetallicRoughness": {"baseColorTexture": {"index": t}}})
+        pos = b.accessor(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], f32), "VEC3")
+        b.doc["meshes"].append({"primitives": [{"attributes": {"POSITION": pos}, "material": 0}]})
+        b.doc["nodes"].append({"mesh": 0})
+        b.doc["scenes"].append({"nodes": [0]})
+        path = str(tmp_path / f"{name}.glb")
+        b.write(path, glb=True)
+        sc = scene_io.SceneFile.empty().import_gltf(path)
+        sc.add_camera((0, 0, 3), (0, 0, 0))
+        tex = snap_textures(sc.snapshot().struct)
+        assert (tex[0][0], tex[0][1], tex[0][2]) == (want.shape[1], want.shape[0], abi.TEX_RGBA8_SRGB), name
+        assert tex[0][3] == want.tobytes(), name
+    b = sf.GltfBuilder()
+    b.image_png(b"\xff\xd8\xff\xe0" + b"\0" * 64)
+    b.doc["materials"].append({"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}})
+    b.write(str(tmp_path / "jpeg.glb"), glb=True)
+    with pytest.raises(abi.PtamdError, match="JPEG is not supported"):
+        scene_io.SceneFile.empty().import_gltf(str(tmp_path / "jpeg.glb"))
+
+
+# ---- glTF ----------------------------------------------------------------------------------------------------------------
+def quat_from_euler_yxz(rx, ry, rz):
+    """A quaternion for R = Ry * Rx * Rz (the order Transform::matrix composes, core/transform.hpp:47-50)."""
+    def q(axis, a):
+        v = np.zeros(4)
+        v[axis] = np.sin(a / 2)
+        v[3] = np.cos(a / 2)
+        return v
+
+    def mul(a, b):
+        ax, ay, az, aw = a
+        bx, by, bz, bw = b
+        return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                         aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+    return mul(mul(q(1, ry), q(0, rx)), q(2, rz))
+
+
+def build_gltf(tmp_path, kind):
+    ball = scenes.sphere(0.5, 6, 8)
+    quad = scenes.plane(2.0)
+    rng = np.random.default_rng(23)
+    base = rng.integers(0, 256, (6, 5, 4), dtype=np.uint8)
+    base[..., 3] = 255
+    orm = rng.integers(0, 256, (4, 4, 3), dtype=np.uint8)
+    b = sf.GltfBuilder()
+    t_base = b.image_png(sf.png_bytes(base), embed="view" if kind == "glb" else ("data" if kind == "embedded" else "file"),
+                         dirpath=str(tmp_path), name="base colour.png")
+    t_orm = b.image_png(sf.png_bytes(orm), embed="view" if kind == "glb" else "data", name="orm")
+    b.doc["materials"] += [
+        {"name": "painted", "pbrMetallicRoughness": {"baseColorFactor": [0.9, 0.8, 0.7, 1.0], "roughnessFactor": 0.6, "metallicFactor": 0.3,
+                                                       "baseColorTexture": {"index": t_base}, "metallicRoughnessTexture": {"index": t_orm}},
+         "normalTexture": {"index": t_base}, "emissiveFactor": [0.0, 0.0, 0.0],
+         "extensions": {"KHR_materials_clearcoat": {"clearcoatFactor": 0.5, "clearcoatRoughnessFactor": 0.1, "clearcoatTexture": {"index": t_orm}},
+                        "KHR_materials_ior": {"ior": 1.33}}},
+        {"name": "glow", "emissiveFactor": [1.0, 0.5, 0.25], "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 4.0},
+                                                                              "KHR_materials_transmission": {"transmissionFactor": 0.25},
+                                                                              "KHR_materials_anisotropy": {"anisotropyStrength": 0.4, "anisotropyRotation": 1.1}}},
+    ]
+    # mesh 0: the sphere, interleaved POSITION+NORMAL (stride 24), uv as normalized ushort, ushort indices, NO tangents
+    inter = np.concatenate([ball.positions[:, :3], ball.vertex_data[:, 0:3]], 1).astype(f32)
+    v = b.view(inter.tobytes(), stride=24)
+    a_pos = b.accessor(inter, "VEC3", view=v, offset=0)
+    a_nrm = b.accessor(inter, "VEC3", view=v, offset=12)
+    uv16 = np.round(ball.vertex_data[:, 8:10] * 65535.0).astype(np.uint16)
+    a_uv = b.accessor(uv16, "VEC2", component=5123, normalized=True)
+    a_idx = b.accessor(ball.indices.astype(np.uint16), "SCALAR", component=5123)
+    # mesh 1: two primitives (two material slots): the quad with float data + tangents, and a single unindexed triangle without material
+    a_qpos = b.accessor(quad.positions[:, :3].astype(f32), "VEC3")
+    a_qnrm = b.accessor(quad.vertex_data[:, 0:3].astype(f32), "VEC3")
+    a_quv = b.accessor(quad.vertex_data[:, 8:10].astype(f32), "VEC2")
+    a_qtan = b.accessor(np.tile(np.array([[1, 0, 0, 1]], f32), (4, 1)), "VEC4")
+    a_qidx = b.accessor(quad.indices.astype(np.uint32), "SCALAR", component=5125)
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 0, -1]], f32)
+    a_tpos = b.accessor(tri, "VEC3")
+    b.doc["meshes"] += [
+        {"name": "ball", "primitives": [{"attributes": {"POSITION": a_pos, "NORMAL": a_nrm, "TEXCOORD_0": a_uv}, "indices": a_idx, "material": 0}]},
+        {"name": "quad+tri", "primitives": [{"attributes": {"POSITION": a_qpos, "NORMAL": a_qnrm, "TEXCOORD_0": a_quv, "TANGENT": a_qtan},
+                                             "indices": a_qidx, "material": 1},
+                                            {"attributes": {"POSITION": a_tpos}, "mode": 4},
+                                            {"attributes": {"POSITION": a_tpos}, "mode": 1}]},  # lines: skipped with a warning
+    ]
+    b.doc["cameras"] += [{"type": "perspective", "perspective": {"yfov": 0.6, "aspectRatio": 1.6, "znear": 0.1}},
+                         {"type": "orthographic", "orthographic": {"xmag": 1, "ymag": 1, "znear": 0.1, "zfar": 10}}]
+    e = (0.3, -0.8, 0.2)
+    q = quat_from_euler_yxz(*e)
+    M = scenes.mat_mul(scenes.mat_mul(scenes.mat_translation((1, 2, 3)), scenes.mat_rotation_y(0.5)), scenes.mat_scaling((2, 2, 2)))
+    b.doc["nodes"] += [
+        {"name": "trs ball", "mesh": 0, "translation": [0.5, 1.0, -0.5], "rotation": [float(x) for x in q], "scale": [1.0, 2.0, 1.0], "children": [1, 2]},
+        {"name": "matrix child", "mesh": 1, "matrix": [float(x) for x in M.reshape(-1)]},
+        {"name": "empty leaf"},
+        {"name": "eye", "camera": 0, "translation": [0.0, 1.0, 6.0]},
+    ]
+    b.doc["scenes"].append({"nodes": [0, 3]})
+    path = str(tmp_path / ("scene.glb" if kind == "glb" else "scene.gltf"))
+    b.write(path, glb=(kind == "glb"), embed_buffer=(kind == "embedded"))
+    return path, dict(ball=ball, quad=quad, base=base, orm=orm, euler=e, uv16=uv16, tri=tri)
+
+
+@pytest.mark.parametrize("kind", ["glb", "embedded", "external"])
+def test_gltf_import(tmp_path, kind):
+    path, d = build_gltf(tmp_path, kind)
+    sc = scene_io.SceneFile.empty().import_gltf(path, scene_io.GLTF_SKIP_EMPTY_NODES)
+    c = sc.counts()
+    assert (c.meshes, c.textures, c.materials, c.cameras, c.instances) == (2, 2, 2, 1, 2)
+    assert c.nodes == 1 + 3  # root + three nodes; the empty leaf is skipped (LoadOptions_SkipEmptyNodes, gltf.cpp:259-263)
+    assert sc.cameras() == [(3, "eye")]
+    s = sc.snapshot().struct
+    meshes = snap_meshes(s)
+    ball, quad = d["ball"], d["quad"]
+    # mesh 0: positions / normals verbatim, uv = ushort / 65535, tangents generated by MikkTSpace (no TANGENT attribute)
+    pos, vd, idx, sl = meshes[0]
+    assert np.array_equal(pos[:, :3], ball.positions[:, :3]) and np.array_equal(vd[:, 0:3], ball.vertex_data[:, 0:3])
+    assert np.array_equal(vd[:, 8:10], d["uv16"].astype(f32) / f32(65535.0))
+    assert np.array_equal(idx, ball.indices) and np.all(sl == 0)
+    want_vd = vd.copy()
+    want_vd[:, 4:8] = 0
+    assert np.array_equal(vd[:, 4:8], scene_io.generate_tangents(pos, want_vd, idx)[:, 4:8])
+    assert np.allclose(np.linalg.norm(vd[:, 4:7], axis=1), 1.0, atol=1e-5)
+    # mesh 1: primitives concatenated with index offsets and slot numbers (gltf.cpp:217-230); TANGENT kept; lines skipped
+    pos, vd, idx, sl = meshes[1]
+    assert len(pos) == 4 + 3 and np.array_equal(pos[:4, :3], quad.positions[:, :3]) and np.array_equal(pos[4:, :3], d["tri"])
+    assert np.array_equal(idx, np.concatenate([quad.indices, [4, 5, 6]])) and list(sl) == [0, 0, 1]
+    assert np.array_equal(vd[:4, 4:8], np.tile(np.array([[1, 0, 0, 1]], f32), (4, 1))) and np.all(vd[4:, 0:3] == 0)
+    # textures in first-use order with their TextureType conversion (texture.cpp:30-48): base sRGB RGBA8, ORM -> RG8 = (G, B)
+    # NB the same glTF texture used for base colour AND normal keeps the LAST registered type (gltf.cpp:343-366): LinearRGB
+    tex = snap_textures(s)
+    assert (tex[0][0], tex[0][1], tex[0][2]) == (5, 6, abi.TEX_RGBA8) and tex[0][3] == d["base"].tobytes()
+    assert (tex[1][0], tex[1][1], tex[1][2]) == (4, 4, abi.TEX_R8) and tex[1][3] == d["orm"][..., 0].tobytes()  # clearcoat (Mono) registered last
+    inst = snap_instances(s)
+    # traversal is LIFO: scene nodes [trs ball, eye]; children of "trs ball" after it
+    assert [i[0] for i in inst] == [0, 1]
+    painted = inst[0][2][0]
+    assert np.allclose(tuple(painted.baseColor), (0.9, 0.8, 0.7, 1.0)) and painted.roughness == f32(0.6) and painted.metallic == f32(0.3)
+    assert (painted.baseTextureId, painted.normalTextureId, painted.rmTextureId, painted.clearcoatTextureId) == (0, 0, 1, 1)
+    assert painted.clearcoat == 0.5 and painted.clearcoatRoughness == f32(0.1) and painted.ior == f32(1.33)
+    assert painted.emissionStrength == 1.0 and painted.flags == 0  # fastgltf default strength 1, factor 0 => not emissive
+    glow, none = inst[1][2]
+    assert glow.flags == abi.MATERIAL_EMISSIVE | abi.MATERIAL_ANISOTROPIC and glow.emissionStrength == 4.0 and glow.transmission == 0.25
+    assert glow.metallic == 1.0 and glow.roughness == 1.0 and glow.anisotropyRotation == f32(1.1)
+    # a primitive without material gets asset id 0 (gltf.cpp:234-235) — here that IS the first material ("painted")
+    assert bytes(none) == bytes(painted)
+    # node transforms: quaternion -> eulerFromQuat (gltf.cpp:9-17) -> Transform::matrix = T*Ry*Rx*Rz*S.  The reference's
+    # formula is the heading/attitude/bank extraction (R = Ry*Rz*Rx) with the asin argument clamped to +-0.5, which is NOT
+    # the inverse of its own Ry*Rx*Rz composition for a general rotation: a drop-in reproduces that, it does not fix it.
+    qx, qy, qz, qw = [f32(v) for v in quat_from_euler_yxz(*d["euler"])]
+    two, one = f32(2), f32(1)
+    e = (np.arctan2(two * (qw * qx - qy * qz), one - two * (qx * qx + qz * qz)),
+         np.arctan2(two * (qw * qy - qx * qz), one - two * (qy * qy + qz * qz)),
+         np.arcsin(two * np.clip(qx * qy + qw * qz, f32(-0.5), f32(0.5))))
+    Tr = scenes.Transform
+    w0 = Tr(translation=(0.5, 1.0, -0.5), rotation=e, scale=(1, 2, 1)).matrix()
+    np.testing.assert_allclose(inst[0][1], w0[:, :3], rtol=1e-5, atol=2e-6)
+    M = scenes.mat_mul(scenes.mat_mul(scenes.mat_translation((1, 2, 3)), scenes.mat_rotation_y(0.5)), scenes.mat_scaling((2, 2, 2)))
+    np.testing.assert_allclose(inst[1][1], scenes.mat_mul(w0, M)[:, :3], rtol=1e-5, atol=5e-6)  # matrix decomposed (fastgltf math.hpp:854-891)
+    # camera: Camera::withFov(yfov, {24 * aspect, 24}) (gltf.cpp:83-91, core/camera.hpp:32-42); orthographic ones are dropped
+    assert np.isclose(s.camera.sensor_size[0], 24 * 1.6) and s.camera.sensor_size[1] == 24.0
+    assert np.isclose(s.camera.focal_length, 24.0 / (2 * np.tan(0.3)), rtol=1e-6)
+    # renders
+    o = oracle_lib.OracleScene(sc, make_params(48, 30, 1, 4))
+    rad, hits = o.debug_sample(0)
+    assert np.isfinite(rad).all() and (hits[0, ..., 0] >= 0).any()
+
+
+def test_gltf_create_scene_nodes_option_and_errors(tmp_path):
+    path, _ = build_gltf(tmp_path, "glb")
+    sc = scene_io.SceneFile.empty().import_gltf(path, scene_io.GLTF_CREATE_SCENE_NODES)
+    assert sc.counts().nodes == 1 + 1 + 4  # root, the "scene" node named after the file, all four nodes (empty leaf kept)
+    with pytest.raises(abi.PtamdError, match="cannot open"):
+        scene_io.SceneFile.empty().import_gltf(str(tmp_path / "nope.gltf"))
+    bad = tmp_path / "bad.gltf"
+    bad.write_text(json.dumps({"asset": {"version": "2.0"}, "buffers": [{"byteLength": 4, "uri": "data:application/octet-stream;base64,AAAAAA=="}],
+                               "bufferViews": [{"buffer": 0, "byteLength": 4}],
+                               "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}],
+                               "meshes": [{"primitives": [{"attributes": {"POSITION": 0}}]}]}))
+    with pytest.raises(abi.PtamdError, match="accessor exceeds its bufferView"):
+        scene_io.SceneFile.empty().import_gltf(str(bad))

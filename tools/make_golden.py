@@ -10,6 +10,9 @@ as small fixtures under tests/golden/.  Re-running must reproduce the files bit-
                           per-channel means and a sha256 of the full images; primary-ray (instance, primitive) map
                           checksum and a 64x64 crop of (t,u,v)
   c2_small_golden.npz     Cornell + glass sphere, 160x90, 8 bounces: full accumulator at 2 spp + per-bounce hit ids of sample 0
+  mikkt_tangents.npz      tangents of five meshes computed by the REFERENCE's deps/mikkt/mikktspace.c (compiled where it lies into
+                          oracle/_ref/libmikkt.so) through the callbacks of core/mesh.cpp:11-57
+  scene_fixture/mini.*    a scene.json + _data.bin pair in the reference's format (tests/scene_formats.py restates saveToFile)
   n3_textured_golden.npz  scenes.textured_scene() (textures, normal map, cut-outs, environment), 96x54, 6 bounces: accumulator
                           at 2 spp, per-bounce hit ids of sample 0, the environment alias table
 """
@@ -61,5 +64,20 @@ rad3, hits3 = o3.debug_sample(0)
 al = o3.envAlias()
 np.savez_compressed(os.path.join(G, "n3_textured_golden.npz"), acc2=acc3, hits0=hits3.astype(np.int16),
                     alias_pdf=al["pdf"], alias_p=al["p"], alias_idx=al["aliasIdx"])
+# ---- N4: tangents from the reference's own mikktspace.c (oracle/_ref/libmikkt.so) and the scene.json fixture ----
+import scene_formats as sf
+import test_scene_ingestion as tsi
+if sf.mikkt_available():
+    tang = {}
+    for name, m in tsi.tangent_cases().items():
+        vd = np.ascontiguousarray(m.vertex_data, dtype=np.float32).copy()
+        vd[:, 4:8] = 0
+        tang[name] = sf.mikkt_reference_tangents(m.positions, vd, m.indices)
+    np.savez_compressed(os.path.join(G, "mikkt_tangents.npz"), **tang)
+else:
+    print("oracle/_ref/libmikkt.so not built (make -C oracle ref): mikkt_tangents.npz left as is")
+os.makedirs(os.path.join(G, "scene_fixture"), exist_ok=True)
+assets, root, envmap, _ = tsi.mini_scene_spec()
+sf.write_reference_scene(os.path.join(G, "scene_fixture", "mini.json"), assets, root, envmap)
 for f in sorted(os.listdir(G)):
     print(f, os.path.getsize(os.path.join(G, f)))
