@@ -339,7 +339,14 @@ def test_ingested_scene_json_fixture_parity(gpu_renderer):
     assert gpu_renderer.readbackAccumulator().tobytes() == o.render(0, 3).tobytes()
 
 
+def _same_bits_or_both_nan(a, b):
+    """Bitwise equality, except that NaNs only have to coincide: x86 and gfx950 produce default NaNs of opposite sign."""
+    nan = np.isnan(a)
+    return np.array_equal(nan, np.isnan(b)) and np.array_equal(a.view(np.uint32)[~nan], b.view(np.uint32)[~nan])
+
+
 def test_ingested_gltf_parity(gpu_renderer, tmp_path):
+    """(The glTF has one triangle without normals — zero-length shading normal — so a few paths are NaN on both sides.)"""
     from platinum_amd import scene_io
     import test_scene_ingestion as tsi
     path, _ = tsi.build_gltf(tmp_path, "glb")
@@ -350,5 +357,5 @@ def test_ingested_gltf_parity(gpu_renderer, tmp_path):
     for s in (0, 1):
         rg, hg = gpu_renderer.debugSample(s)
         rc, hc = o.debug_sample(s)
-        assert np.array_equal(hg, hc) and rg.tobytes() == rc.tobytes()
-    assert (hc[0, ..., 0] >= 0).mean() > 0.05 and rc[..., :3].mean() > 1e-3
+        assert np.array_equal(hg, hc) and _same_bits_or_both_nan(rg, rc)
+    assert (hc[0, ..., 0] >= 0).mean() > 0.05 and np.nanmean(rc[..., :3]) > 1e-3 and np.isnan(rc).mean() < 0.01
