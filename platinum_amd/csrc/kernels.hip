@@ -197,6 +197,49 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DeviceScene S, PathState st, 
   }
 }
 
+// ---- wave-cooperative traversal step ---------------------------------------------------------------------------------
+// One iteration for the lanes of a wave that still hold a ray: (1) lanes with a node to visit and room in their leaf
+// queue visit it (trav_node: slab tests, candidate leaves queued, next node chosen); (2) the wave votes — when at least
+// half of these lanes have a queued leaf, or a lane cannot go on without emptying its queue (queue full, or node stack
+// exhausted with nobody else able to advance), every lane with a queued leaf runs ONE triangle test.  The triangle code
+// therefore executes with most lanes busy instead of whenever a single lane met a leaf.  A ray is finished when its node
+// stack is exhausted and its queue is empty (any-hit: on the first accepted hit).
+#ifndef PT_FULL_LANES
+#define PT_FULL_LANES 64  /* lanes with a full queue needed to force a triangle round = 64 / PT_FULL_LANES */
+#endif
+#ifndef PT_GO_NUM
+#define PT_GO_NUM 1
+#define PT_GO_DEN 2
+#endif
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void wave_traverse(const DeviceScene& S, TravState& ts, TraversalCount* tc) {
+#ifdef PT_WAVE_COUNT
+  TraversalCount dummy;
+  const bool first = (int)__builtin_ctzll(__ballot(1)) == (int)(threadIdx.x & 63);
+  const bool donode = ts.cur != kInvalidRef && ts.st.npend <= kPendLeaves - 4;
+  if (COUNT && first && __ballot(donode) != 0) tc->nodes += 64;
+  if (donode) trav_node<false>(S, ts, &dummy);
+#else
+  if (ts.cur != kInvalidRef && ts.st.npend <= kPendLeaves - 4) trav_node<COUNT>(S, ts, tc);
+#endif
+  const bool pending = ts.st.npend > 0;
+  const bool stuck = pending && (ts.cur == kInvalidRef || ts.st.npend > kPendLeaves - 4);
+  const bool advancing = ts.cur != kInvalidRef && !stuck;
+  const unsigned long long mp = __ballot(pending);
+  if (mp == 0) return;
+  const bool go = PT_GO_DEN * __popcll(mp) >= PT_GO_NUM * __popcll(__ballot(1)) || PT_FULL_LANES * __popcll(__ballot(ts.st.npend > kPendLeaves - 4)) >= 64 || __ballot(advancing) == 0;
+#ifdef PT_WAVE_COUNT
+  if (COUNT && first && go) tc->tris += 64;
+  if (go && pending) {
+    if (trav_pending_leaf<ANY, false>(S, ts, &dummy)) { ts.cur = kInvalidRef; ts.st.npend = 0; ts.st.sp = 0; }
+  }
+#else
+  if (go && pending) {
+    if (trav_pending_leaf<ANY, COUNT>(S, ts, tc)) { ts.cur = kInvalidRef; ts.st.npend = 0; ts.st.sp = 0; }
+  }
+#endif
+}
+
 // ---- closest hit ---------------------------------------------------------------------------------------------------
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock) k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments seg,
@@ -204,11 +247,13 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DeviceScene S, PathSta
                                                            uint32_t* __restrict__ spill, int32_t* __restrict__ hitlog,
                                                            uint32_t log_stride) {
   __shared__ uint32_t lds_stack[kLdsStack][kBlock];
+  __shared__ uint32_t lds_pend[kPendLeaves][kBlock];
   const uint32_t lane = wave_lane();
   ChunkClaims src;
   src.init(seg.table_closest, ctr->chunks_closest[bounce], seg.active[cur], &ctr->work_closest[bounce], seg, lane);
   TraversalStack stack;
   stack.lds = &lds_stack[0][threadIdx.x];
+  stack.pend = &lds_pend[0][threadIdx.x];
   stack.lds_stride = kBlock;
   stack.spill = spill + ((size_t)blockIdx.x * kBlock + threadIdx.x);
   stack.spill_stride = gridDim.x * kBlock;
@@ -245,7 +290,8 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DeviceScene S, PathSta
       continue;
     }
     while (ray != kInvalidRef) {
-      if (trav_step<false, COUNT>(S, ts, &tc)) finish();
+      wave_traverse<false, COUNT>(S, ts, &tc);
+      if (ts.cur == kInvalidRef && ts.st.npend == 0) finish();
       // lanes still in this loop vote: leave for a refill once the wave has emptied below the threshold
       if (refill && !src.exhausted && (uint32_t)__popcll(__ballot(ray != kInvalidRef)) < refill) break;
     }
@@ -365,11 +411,13 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow(DeviceScene S, ShadowQu
                                                           BatchCounters* __restrict__ ctr, uint32_t bounce,
                                                           uint32_t* __restrict__ spill) {
   __shared__ uint32_t lds_stack[kLdsStack][kBlock];
+  __shared__ uint32_t lds_pend[kPendLeaves][kBlock];
   const uint32_t lane = wave_lane();
   ChunkClaims src;
   src.init(seg.table_shadow, ctr->chunks_shadow[bounce], seg.shadow, &ctr->work_shadow[bounce], seg, lane);
   TraversalStack stack;
   stack.lds = &lds_stack[0][threadIdx.x];
+  stack.pend = &lds_pend[0][threadIdx.x];
   stack.lds_stride = kBlock;
   stack.spill = spill + ((size_t)blockIdx.x * kBlock + threadIdx.x);
   stack.spill_stride = gridDim.x * kBlock;
@@ -404,7 +452,8 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow(DeviceScene S, ShadowQu
       continue;
     }
     while (ray != kInvalidRef) {
-      if (trav_step<true, COUNT>(S, ts, &tc)) finish();
+      wave_traverse<true, COUNT>(S, ts, &tc);
+      if (ts.cur == kInvalidRef && ts.st.npend == 0) finish();
       if (refill && !src.exhausted && (uint32_t)__popcll(__ballot(ray != kInvalidRef)) < refill) break;
     }
   }

@@ -63,12 +63,18 @@ constexpr int kLdsStack = 16;
 constexpr int kSpillStack = 80;  // total 96 entries: up to 3 pushes per level of a 4-wide tree that is <= 48 levels deep
                                  // (binary LBVH depth <= 95 over 63-bit codes + index tie-break, halved by the collapse)
 
+constexpr int kPendLeaves = 8;   // per-lane queue of leaf candidates awaiting their triangle test (LDS, [slot][lane])
+
 struct TraversalStack {
   uint32_t* lds;     // &lds_stack[0][lane_in_block]
   int lds_stride;    // block size
   uint32_t* spill;   // &spill[0][global_thread]
   int spill_stride;  // threads in grid
+  uint32_t* pend;    // &lds_pending[0][lane_in_block], stride lds_stride
   int sp = 0;
+  int npend = 0;
+  PT_HD void push_leaf(uint32_t ref) { pend[npend * lds_stride] = ref; npend++; }
+  PT_HD uint32_t pop_leaf() { npend--; return pend[npend * lds_stride]; }
   PT_HD void push(uint32_t v) {
     if (sp < kLdsStack) lds[sp * lds_stride] = v;
     else if (sp < kLdsStack + kSpillStack) spill[(size_t)(sp - kLdsStack) * spill_stride] = v;
@@ -84,8 +90,9 @@ struct TraversalStack {
 
 struct TraversalCount { uint32_t nodes = 0, tris = 0; };
 
-// Resumable traversal: one ray's state lives in registers (+ its LDS/HBM stack) and advances one node per
-// trav_step(), so a persistent kernel can hand a finished lane a new ray while its neighbours keep going.
+// Resumable traversal: one ray's state lives in registers (+ its LDS/HBM stack and leaf queue) and advances one node
+// per trav_node() / one triangle per trav_pending_leaf(), so a persistent kernel can hand a finished lane a new ray
+// while its neighbours keep going, and can run the triangle test for many lanes at once (see k_trace_closest).
 struct TravState {
   vec3 o, d, inv;
   float tmin;
@@ -140,6 +147,7 @@ PT_HD bool trav_init(const DeviceScene& S, TravState& ts, vec3 o, vec3 d, float 
   ts.best.t = tmax; ts.best.u = ts.best.v = 0.0f; ts.best.tri = kInvalidRef; ts.best.gid = kInvalidRef;
   ts.st = st;
   ts.st.sp = 0;
+  ts.st.npend = 0;
   ts.cur = S.root_ref;
   if (S.root_ref == kInvalidRef) return true;
   if (S.root_ref & kLeafBit) {  // single-triangle scene
@@ -217,19 +225,20 @@ PT_HD Box3 inflate_box(const Box3& b) {
   return r;
 }
 
-// One node per call.  The node's four child slabs are evaluated in "ray space": with A = scale * inv_d and
-// B = (origin - o) * inv_d per axis, t(q) = q * A + B (3 VALU per coordinate instead of 5).  This rounds differently
-// from the builder's origin + q * scale, by a few ulp of t; the slab slack and the 8e-6 box inflation absorb that.
-// Leaf children that pass the slab test are collected first and then tested by ONE copy of the triangle code in a
-// short loop, so a wave does not serialise through four inlined copies of it.
-template <bool ANY, bool COUNT>
-PT_HD bool trav_step(const DeviceScene& S, TravState& ts, TraversalCount* cnt) {
+// One node per call (ts.cur must be a node and the leaf queue must have room for four entries).  The node's four child
+// slabs are evaluated in "ray space": with A = scale * inv_d and B = (origin - o) * inv_d per axis, t(q) = q * A + B
+// (3 VALU per coordinate instead of 5).  This rounds differently from the builder's origin + q * scale, by a few ulp of
+// t; the slab slack and the 8e-6 box inflation absorb that.  Leaf children that pass the slab test are NOT tested here:
+// they go to the lane's leaf queue, and the caller runs the triangle code when enough lanes of the wave have one queued
+// (measured before this split: the in-place triangle loop ran at 11 % lane utilisation on C2, 8 % on C3).
+// On return ts.cur is the next node, or kInvalidRef when the node stack is exhausted.
+template <bool COUNT>
+PT_HD void trav_node(const DeviceScene& S, TravState& ts, TraversalCount* cnt) {
   const BvhNode n = S.nodes[ts.cur];
   if (COUNT) cnt->nodes++;
   const float ax = node_scale(n.exp[0]) * ts.inv.x, ay = node_scale(n.exp[1]) * ts.inv.y, az = node_scale(n.exp[2]) * ts.inv.z;
   const float bx = (n.origin[0] - ts.o.x) * ts.inv.x, by = (n.origin[1] - ts.o.y) * ts.inv.y, bz = (n.origin[2] - ts.o.z) * ts.inv.z;
   float dist[4];
-  uint32_t leaf_mask = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     float t0 = (float)n.qlo[k][0] * ax + bx, t1 = (float)n.qhi[k][0] * ax + bx;
@@ -244,18 +253,9 @@ PT_HD bool trav_step(const DeviceScene& S, TravState& ts, TraversalCount* cnt) {
     const bool hit = n.ref[k] != kInvalidRef && tn <= tf * 1.0000005f + 1e-30f;
     dist[k] = hit ? tn : kInf;
     if (hit && (n.ref[k] & kLeafBit)) {
-      leaf_mask |= 1u << k;
-      dist[k] = kInf;  // leaves never go on the stack
+      ts.st.push_leaf(n.ref[k]);
+      dist[k] = kInf;  // leaves never go on the node stack
     }
-  }
-  // triangle phase: one code copy, as many iterations as this lane has candidate leaves
-  while (leaf_mask) {
-    const uint32_t k = leaf_mask & 1u ? 0u : (leaf_mask & 2u ? 1u : (leaf_mask & 4u ? 2u : 3u));
-    leaf_mask &= leaf_mask - 1u;
-    const uint32_t ref = k == 0 ? n.ref[0] : (k == 1 ? n.ref[1] : (k == 2 ? n.ref[2] : n.ref[3]));
-    bool finished = false;
-    trav_leaf(S, ts, ref, ANY, &finished, COUNT ? cnt : nullptr);
-    if (finished) return true;
   }
   // internal children: nearest becomes `cur`, the others are pushed far-to-near
   // (5-comparator sorting network on (dist, ref) pairs; misses carry +inf and sink to the end)
@@ -265,19 +265,32 @@ PT_HD bool trav_step(const DeviceScene& S, TravState& ts, TraversalCount* cnt) {
                                    db = sw ? da : db; rb = sw ? ra : rb; da = td; ra = tr; }
   PT_CSWAP(d0, r0, d1, r1) PT_CSWAP(d2, r2, d3, r3) PT_CSWAP(d0, r0, d2, r2) PT_CSWAP(d1, r1, d3, r3) PT_CSWAP(d1, r1, d2, r2)
 #undef PT_CSWAP
-  // children that fell behind the (possibly just shortened) best.t are dropped here instead of being visited
-  const float limit = fminf(ts.best.t * 1.0000005f + 1e-30f, 3.0e38f);  // finite, so the +inf of a miss never passes
-  if (d0 <= limit) {
-    if (d3 <= limit) ts.st.push(r3);
-    if (d2 <= limit) ts.st.push(r2);
-    if (d1 <= limit) ts.st.push(r1);
+  if (d0 < kInf) {
+    if (d3 < kInf) ts.st.push(r3);
+    if (d2 < kInf) ts.st.push(r2);
+    if (d1 < kInf) ts.st.push(r1);
     ts.cur = r0;
   } else {
-    if (ts.st.sp == 0) return true;
-    ts.cur = ts.st.pop();
-    if (ts.cur == kInvalidRef) return true;
+    ts.cur = ts.st.sp == 0 ? kInvalidRef : ts.st.pop();
   }
-  return false;
+}
+
+// Tests one queued leaf.  Returns true when an any-hit ray is finished by it.
+template <bool ANY, bool COUNT>
+PT_HD bool trav_pending_leaf(const DeviceScene& S, TravState& ts, TraversalCount* cnt) {
+  bool finished = false;
+  trav_leaf(S, ts, ts.st.pop_leaf(), ANY, &finished, COUNT ? cnt : nullptr);
+  return finished;
+}
+
+// One node, then its leaves at once (the scalar formulation: tests/emu, and the reference for the wave-cooperative
+// scheduling in kernels.hip — the answer does not depend on the order in which candidates are tested).
+template <bool ANY, bool COUNT>
+PT_HD bool trav_step(const DeviceScene& S, TravState& ts, TraversalCount* cnt) {
+  trav_node<COUNT>(S, ts, cnt);
+  while (ts.st.npend > 0)
+    if (trav_pending_leaf<ANY, COUNT>(S, ts, cnt)) return true;
+  return ts.cur == kInvalidRef;
 }
 
 template <bool ANY, bool COUNT>

@@ -150,7 +150,7 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
   const DeviceScene& S = e->S;
   const uint32_t W = S.width, H = S.height, B = S.max_bounces, NP = W * H;
   if (hits) for (size_t i = 0; i < (size_t)B * NP * 2; i++) hits[i] = -1;
-  std::vector<uint32_t> lds(kLdsStack), spill(kSpillStack);
+  std::vector<uint32_t> lds(kLdsStack), spill(kSpillStack), pend(kPendLeaves);
   for (uint32_t y = 0; y < H; y++)
     for (uint32_t x = 0; x < W; x++) {
       const uint32_t pid = y * W + x;
@@ -158,7 +158,7 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
       vec3 o = rg.o, d = rg.d, att = v3(1.0f), L = v3(0.0f);
       float lastPdf = 0.0f; bool lastSpec = false; uint32_t dim = rg.dim;
       for (uint32_t b = 0; b < B; b++) {
-        TraversalStack st; st.lds = lds.data(); st.lds_stride = 1; st.spill = spill.data(); st.spill_stride = 1;
+        TraversalStack st; st.lds = lds.data(); st.pend = pend.data(); st.lds_stride = 1; st.spill = spill.data(); st.spill_stride = 1;
         TraversalCount tc;
         const float ir = S.has_alpha ? Halton{S.halton, rg.offset, dim}.sample1d() : 0.0f;
         RayHit hit = traverse<false, false>(S, o, d, 1e-3f, kInf, ir, st, &tc);
@@ -186,11 +186,11 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
 void emu_trace_primary(void* h, uint32_t sample, pt_hit_record* out) {
   Emu* e = (Emu*)h;
   const DeviceScene& S = e->S;
-  std::vector<uint32_t> lds(kLdsStack), spill(kSpillStack);
+  std::vector<uint32_t> lds(kLdsStack), spill(kSpillStack), pend(kPendLeaves);
   for (uint32_t y = 0; y < S.height; y++)
     for (uint32_t x = 0; x < S.width; x++) {
       RayGenOut rg = stage_raygen(S, x, y, sample);
-      TraversalStack st; st.lds = lds.data(); st.lds_stride = 1; st.spill = spill.data(); st.spill_stride = 1;
+      TraversalStack st; st.lds = lds.data(); st.pend = pend.data(); st.lds_stride = 1; st.spill = spill.data(); st.spill_stride = 1;
       TraversalCount tc;
       const float ir = S.has_alpha ? Halton{S.halton, rg.offset, rg.dim}.sample1d() : 0.0f;
       RayHit hit = traverse<false, false>(S, rg.o, rg.d, 1e-3f, kInf, ir, st, &tc);
