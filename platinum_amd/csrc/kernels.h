@@ -32,7 +32,7 @@ void launch_chunk_tables(hipStream_t s, Segments seg, uint32_t cur, BatchCounter
                          uint32_t bounce_shadow, bool do_shadow);
 void launch_trace_closest(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, vec4* hit, Segments seg, uint32_t cur,
                           BatchCounters* ctr, uint32_t bounce, uint32_t* spill, int32_t* hitlog, uint32_t log_stride, bool count);
-void launch_shade(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState sin, PathState sout, const vec4* hit,
+void launch_shade(hipStream_t s, uint32_t grid, const DeviceScene* S_device, PathState sin, PathState sout, const vec4* hit,
                   ShadowQueue sq, vec4* Lbuf, Segments seg, uint32_t cur, BatchCounters* ctr, uint32_t bounce);
 void launch_trace_shadow(hipStream_t s, uint32_t grid, const DeviceScene& S, ShadowQueue sq, vec4* Lbuf, Segments seg,
                          BatchCounters* ctr, uint32_t bounce, uint32_t* spill, bool count);

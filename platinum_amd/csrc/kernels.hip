@@ -309,10 +309,11 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DeviceScene S, PathSta
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 2
 #endif
-__global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(DeviceScene S, PathState sin, PathState sout,
+__global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout,
                                                                    const vec4* __restrict__ hit, ShadowQueue sq,
                                                                    vec4* __restrict__ Lbuf, Segments seg, uint32_t cur,
                                                                    BatchCounters* __restrict__ ctr, uint32_t bounce) {
+  const DeviceScene& S = *Sp;  // scene table read through the scalar cache: by value it cost 100 spilled SGPRs here
   const uint32_t lane = wave_lane();
   const uint32_t w = wave_index();
   const uint32_t n = seg.active[cur][w];
@@ -632,7 +633,7 @@ void launch_trace_closest(hipStream_t s, uint32_t grid, const DeviceScene& S, Pa
   else
     hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(kBlock), 0, s, S, st, hit, seg, cur, ctr, bounce, spill, hitlog, log_stride);
 }
-void launch_shade(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState sin, PathState sout, const vec4* hit,
+void launch_shade(hipStream_t s, uint32_t grid, const DeviceScene* S, PathState sin, PathState sout, const vec4* hit,
                   ShadowQueue sq, vec4* Lbuf, Segments seg, uint32_t cur, BatchCounters* ctr, uint32_t bounce) {
   hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, s, S, sin, sout, hit, sq, Lbuf, seg, cur, ctr, bounce);
 }

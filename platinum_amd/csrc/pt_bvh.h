@@ -95,6 +95,7 @@ struct TraversalCount { uint32_t nodes = 0, tris = 0; };
 // while its neighbours keep going, and can run the triangle test for many lanes at once (see k_trace_closest).
 struct TravState {
   vec3 o, d, inv;
+  bool negx, negy, negz;  // direction signs: which side of a child box the ray enters through
   float tmin;
   RayHit best;     // best.t doubles as the current far limit
   uint32_t cur;    // node to visit next
@@ -144,6 +145,7 @@ PT_HD bool trav_init(const DeviceScene& S, TravState& ts, vec3 o, vec3 d, float 
                      bool any, TraversalCount* cnt) {
   ts.o = o; ts.d = d; ts.tmin = tmin; ts.payload = payload;
   ts.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  ts.negx = ts.inv.x < 0.0f; ts.negy = ts.inv.y < 0.0f; ts.negz = ts.inv.z < 0.0f;
   ts.best.t = tmax; ts.best.u = ts.best.v = 0.0f; ts.best.tri = kInvalidRef; ts.best.gid = kInvalidRef;
   ts.st = st;
   ts.st.sp = 0;
@@ -189,10 +191,11 @@ PT_HD BvhNode quantize_node4(const Box3* boxes, const uint32_t* refs, int count)
   }
   n._pad0 = 0;
   n._pad1[0] = n._pad1[1] = 0;
+  for (int a = 0; a < 3; a++) n.qlo[a] = n.qhi[a] = 0;
   for (int k = 0; k < 4; k++) {
     if (k >= count) {
       n.ref[k] = kInvalidRef;
-      for (int a = 0; a < 3; a++) { n.qlo[k][a] = 255; n.qhi[k][a] = 0; }
+      for (int a = 0; a < 3; a++) n.qlo[a] |= 255u << (8 * k);  // inverted box (lo 255, hi 0)
       continue;
     }
     n.ref[k] = refs[k];
@@ -204,8 +207,8 @@ PT_HD BvhNode quantize_node4(const Box3* boxes, const uint32_t* refs, int count)
       int qh = (int)ceilf((boxes[k].hi[a] - lo[a]) * inv);
       qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
       while (qh < 255 && lo[a] + (float)qh * scale[a] < boxes[k].hi[a]) qh++;
-      n.qlo[k][a] = (uint8_t)ql;
-      n.qhi[k][a] = (uint8_t)qh;
+      n.qlo[a] |= (uint32_t)ql << (8 * k);
+      n.qhi[a] |= (uint32_t)qh << (8 * k);
     }
   }
   return n;
@@ -238,19 +241,21 @@ PT_HD void trav_node(const DeviceScene& S, TravState& ts, TraversalCount* cnt) {
   if (COUNT) cnt->nodes++;
   const float ax = node_scale(n.exp[0]) * ts.inv.x, ay = node_scale(n.exp[1]) * ts.inv.y, az = node_scale(n.exp[2]) * ts.inv.z;
   const float bx = (n.origin[0] - ts.o.x) * ts.inv.x, by = (n.origin[1] - ts.o.y) * ts.inv.y, bz = (n.origin[2] - ts.o.z) * ts.inv.z;
+  // entry / exit planes per axis by direction sign (one select per dword instead of a min/max pair per child)
+  const uint32_t nx = ts.negx ? n.qhi[0] : n.qlo[0], fx = ts.negx ? n.qlo[0] : n.qhi[0];
+  const uint32_t ny = ts.negy ? n.qhi[1] : n.qlo[1], fy = ts.negy ? n.qlo[1] : n.qhi[1];
+  const uint32_t nz = ts.negz ? n.qhi[2] : n.qlo[2], fz = ts.negz ? n.qlo[2] : n.qhi[2];
   float dist[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    float t0 = (float)n.qlo[k][0] * ax + bx, t1 = (float)n.qhi[k][0] * ax + bx;
-    float tn = fmaxf(ts.tmin, fminf(t0, t1));
-    float tf = fminf(ts.best.t, fmaxf(t0, t1));
-    t0 = (float)n.qlo[k][1] * ay + by; t1 = (float)n.qhi[k][1] * ay + by;
-    tn = fmaxf(tn, fminf(t0, t1));
-    tf = fminf(tf, fmaxf(t0, t1));
-    t0 = (float)n.qlo[k][2] * az + bz; t1 = (float)n.qhi[k][2] * az + bz;
-    tn = fmaxf(tn, fminf(t0, t1));
-    tf = fminf(tf, fmaxf(t0, t1));
-    const bool hit = n.ref[k] != kInvalidRef && tn <= tf * 1.0000005f + 1e-30f;
+    // (fused multiply-adds: this arithmetic only has to be conservative, not reproducible — a NaN from 0 * inf is
+    //  dropped by fmax/fmin, which widens the box)
+    const float tnx = __builtin_fmaf((float)((nx >> (8 * k)) & 0xffu), ax, bx), tfx = __builtin_fmaf((float)((fx >> (8 * k)) & 0xffu), ax, bx);
+    const float tny = __builtin_fmaf((float)((ny >> (8 * k)) & 0xffu), ay, by), tfy = __builtin_fmaf((float)((fy >> (8 * k)) & 0xffu), ay, by);
+    const float tnz = __builtin_fmaf((float)((nz >> (8 * k)) & 0xffu), az, bz), tfz = __builtin_fmaf((float)((fz >> (8 * k)) & 0xffu), az, bz);
+    const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), ts.tmin);
+    const float tf = fminf(fminf(fminf(tfx, tfy), tfz), ts.best.t);
+    const bool hit = n.ref[k] != kInvalidRef && tn <= __builtin_fmaf(tf, 1.0000005f, 1e-30f);
     dist[k] = hit ? tn : kInf;
     if (hit && (n.ref[k] & kLeafBit)) {
       ts.st.push_leaf(n.ref[k]);

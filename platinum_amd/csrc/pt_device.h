@@ -43,7 +43,9 @@ static_assert(sizeof(TriRec) == 48, "TriRec");
 // 4-wide BVH node with child boxes quantised to 8 bits per coordinate relative to the node's own box, 64 B =
 // 4 x dwordx4 (one half of a 128-B L2 line).  The traversal kernels are bound by vector-L1 lookups,
 // so the node packs four children into the bytes a binary node needed for two.
-//   child k box:  lo_a = origin[a] + qlo[k][a] * scale[a],  hi_a = origin[a] + qhi[k][a] * scale[a]
+//   child k box:  lo_a = origin[a] + byte_k(qlo[a]) * scale[a],  hi_a = origin[a] + byte_k(qhi[a]) * scale[a]
+//   (one dword per axis and side, child k in byte k: the traversal picks the near/far dword of an axis by the sign of
+//   the ray direction with one select and converts bytes with v_cvt_f32_ubyte0..3)
 //   scale[a] = 2^(exp[a] - 127)  (a power of two: the product is exact, the sum rounds once — the builder
 //   quantises against exactly this expression, so the decoded box always contains the exact child box)
 //   ref: kInvalidRef = empty slot; bit31 set = leaf (index into tris[]); else index of an internal node.
@@ -52,8 +54,8 @@ struct alignas(16) BvhNode {
   uint8_t exp[3];
   uint8_t _pad0;
   uint32_t ref[4];
-  uint8_t qlo[4][3];
-  uint8_t qhi[4][3];
+  uint32_t qlo[3];
+  uint32_t qhi[3];
   uint32_t _pad1[2];
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode");

@@ -94,6 +94,7 @@ struct pt_renderer {
   DevBuf<pt_material_gpu> materials;
   DevBuf<pt_area_light> lights_d;
   std::vector<pt_area_light> lights;
+  DevBuf<DeviceScene> scene_d;
   DevBuf<vec4> tex_pixels;            // all textures decoded to linear float4 (host_scene.h decode_textures)
   DevBuf<TexInfo> textures;
   DevBuf<pt_alias_entry> env_alias_d;
@@ -140,7 +141,7 @@ struct pt_renderer {
 
   void free_scene() {
     positions.release(); vdata.release(); indices.release(); slots.release(); meshes.release(); instances.release();
-    materials.release(); lights_d.release(); tex_pixels.release(); textures.release(); env_alias_d.release();
+    materials.release(); lights_d.release(); tex_pixels.release(); textures.release(); env_alias_d.release(); scene_d.release();
     if (bvh.nodes) (void)hipFree(bvh.nodes);
     if (bvh.tris) (void)hipFree(bvh.tris);
     bvh = LbvhResult{};
@@ -198,7 +199,7 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
     }
     {
       ScopedTimer t(r, K_SHADE);
-      launch_shade(s, r->grid, S, r->path_state(cur), r->path_state(cur ^ 1), r->hit.p, r->shadow_queue(), r->Lbuf.p, seg, (uint32_t)cur, ctr, b);
+      launch_shade(s, r->grid, r->scene_d.p, r->path_state(cur), r->path_state(cur ^ 1), r->hit.p, r->shadow_queue(), r->Lbuf.p, seg, (uint32_t)cur, ctr, b);
       // closest-hit list of bounce b + 1 (written to chunks_closest[b + 1]) and shadow list of bounce b
       launch_chunk_tables(s, seg, (uint32_t)(cur ^ 1), ctr, b + 1, b, mis);
     }
@@ -445,6 +446,7 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
     S.tris = r->bvh.tris;
     S.root_ref = r->bvh.root_ref;
   }
+  PT_HIP(r->scene_d.upload(std::vector<DeviceScene>(1, S)));  // k_shade reads the table from memory (scalar loads)
 
   // ---- wavefront buffers ----
   const uint64_t npix = (uint64_t)p->width * p->height;
