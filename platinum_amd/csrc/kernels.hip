@@ -246,8 +246,8 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DeviceScene S, PathSta
                                                            uint32_t cur, BatchCounters* __restrict__ ctr, uint32_t bounce,
                                                            uint32_t* __restrict__ spill, int32_t* __restrict__ hitlog,
                                                            uint32_t log_stride) {
-  __shared__ uint32_t lds_stack[kLdsStack][kBlock];
-  __shared__ uint32_t lds_pend[kPendLeaves][kBlock];
+  __shared__ uint32_t lds_stack[kLdsStack + 1][kBlock];
+  __shared__ uint32_t lds_pend[kPendLeaves + 1][kBlock];
   const uint32_t lane = wave_lane();
   ChunkClaims src;
   src.init(seg.table_closest, ctr->chunks_closest[bounce], seg.active[cur], &ctr->work_closest[bounce], seg, lane);
@@ -411,8 +411,8 @@ template <bool COUNT>
 __global__ void __launch_bounds__(kBlock) k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments seg,
                                                           BatchCounters* __restrict__ ctr, uint32_t bounce,
                                                           uint32_t* __restrict__ spill) {
-  __shared__ uint32_t lds_stack[kLdsStack][kBlock];
-  __shared__ uint32_t lds_pend[kPendLeaves][kBlock];
+  __shared__ uint32_t lds_stack[kLdsStack + 1][kBlock];
+  __shared__ uint32_t lds_pend[kPendLeaves + 1][kBlock];
   const uint32_t lane = wave_lane();
   ChunkClaims src;
   src.init(seg.table_shadow, ctr->chunks_shadow[bounce], seg.shadow, &ctr->work_shadow[bounce], seg, lane);

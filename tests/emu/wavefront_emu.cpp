@@ -150,7 +150,7 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
   const DeviceScene& S = e->S;
   const uint32_t W = S.width, H = S.height, B = S.max_bounces, NP = W * H;
   if (hits) for (size_t i = 0; i < (size_t)B * NP * 2; i++) hits[i] = -1;
-  std::vector<uint32_t> lds(kLdsStack), spill(kSpillStack), pend(kPendLeaves);
+  std::vector<uint32_t> lds(kLdsStack + 1), spill(kSpillStack), pend(kPendLeaves + 1);
   for (uint32_t y = 0; y < H; y++)
     for (uint32_t x = 0; x < W; x++) {
       const uint32_t pid = y * W + x;
@@ -186,7 +186,7 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
 void emu_trace_primary(void* h, uint32_t sample, pt_hit_record* out) {
   Emu* e = (Emu*)h;
   const DeviceScene& S = e->S;
-  std::vector<uint32_t> lds(kLdsStack), spill(kSpillStack), pend(kPendLeaves);
+  std::vector<uint32_t> lds(kLdsStack + 1), spill(kSpillStack), pend(kPendLeaves + 1);
   for (uint32_t y = 0; y < S.height; y++)
     for (uint32_t x = 0; x < S.width; x++) {
       RayGenOut rg = stage_raygen(S, x, y, sample);
