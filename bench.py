@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5"])
     ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -174,7 +174,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": {"c1": "C1 Cornell box 512x512", "c2": "C2 Cornell box + GGX dielectric sphere (6144 tris), 1920x1080",
-                         "c3": "C3 1.04M-triangle instanced sphere field, 1920x1080"}[args.workload],
+                         "c3": "C3 1.04M-triangle instanced sphere field, 1920x1080",
+                         "c5": "C5 procedural Sponza-class atrium (258k tris, textures, cut-outs, 4096x2048 environment), 3840x2160"}[args.workload],
             "width": W, "height": H, "max_bounces": B, "spp_per_step": S, "spp_per_gpu": K * S, "spp_total": K * S * world,
             "integrator": "MIS+NEE", "flags": "MultiscatterGGX", "triangles": int(st.triangles),
             "parallelism": "sample-sharded x%d" % world,

@@ -148,7 +148,14 @@ PT_HD void trav_leaf(const DeviceScene& S, TravState& ts, uint32_t ref, bool any
 PT_HD bool trav_init(const DeviceScene& S, TravState& ts, vec3 o, vec3 d, float tmin, float tmax, float payload, TraversalStack st,
                      bool any, TraversalCount* cnt) {
   ts.o = o; ts.d = d; ts.tmin = tmin; ts.payload = payload;
+  // A zero (or denormal) direction component would give inv = inf and 0 * inf = NaN in the slab arithmetic; NaNs are
+  // dropped by fmin/fmax, i.e. the axis stops constraining anything and an axis-parallel ray walks a large part of the
+  // tree (measured: environment-light shadow rays towards the top row of a lat-long map, direction exactly (0,1,0),
+  // made k_trace_shadow 250x slower).  A huge finite reciprocal keeps the slab test exact in the limit.
   ts.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  if (!(fabsf(ts.inv.x) <= 1e30f)) ts.inv.x = copysignf(1e30f, d.x);
+  if (!(fabsf(ts.inv.y) <= 1e30f)) ts.inv.y = copysignf(1e30f, d.y);
+  if (!(fabsf(ts.inv.z) <= 1e30f)) ts.inv.z = copysignf(1e30f, d.z);
   ts.negx = ts.inv.x < 0.0f; ts.negy = ts.inv.y < 0.0f; ts.negz = ts.inv.z < 0.0f;
   ts.best.t = tmax; ts.best.u = ts.best.v = 0.0f; ts.best.tri = kInvalidRef; ts.best.gid = kInvalidRef;
   ts.st = st;

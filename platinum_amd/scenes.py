@@ -561,9 +561,86 @@ def textured_scene(env=True, area_light=True, alpha=True):
     return sc
 
 
+def atrium_scene(env_size=(4096, 2048), columns=20):
+    """C5 stand-in (BASELINE.json configs[4]: "glTF Sponza-class scene with mixed Lambert/GGX/emissive + EXR envmap"): no
+    Sponza asset exists offline, so this is a procedural colonnade of the same class — ~260 k triangles, textured
+    floor/walls with normal + roughness-metallic maps, GGX metal and glass objects, alpha-tested banners, emissive lamps
+    and a 4096x2048 RGBA32F environment with a sun (8.4 M alias entries, ~100 MB like the 4K EXR the survey names)."""
+    sc = Scene(name="atrium")
+    yy, xx = np.mgrid[0:64, 0:64]
+    tiles = np.zeros((64, 64, 4), dtype=np.uint8)
+    grout = ((xx % 16) < 1) | ((yy % 16) < 1)
+    tiles[..., 0] = np.where(grout, 60, 170 + (_hash_bytes((64, 64), 11) >> 3))
+    tiles[..., 1] = np.where(grout, 55, 150 + (_hash_bytes((64, 64), 12) >> 3))
+    tiles[..., 2] = np.where(grout, 50, 120 + (_hash_bytes((64, 64), 13) >> 3))
+    tiles[..., 3] = 255
+    t_tiles = sc.add_texture(tiles, abi.TEX_RGBA8_SRGB)
+    rm = np.zeros((64, 64, 2), dtype=np.uint8)
+    rm[..., 0] = np.where(grout, 230, 60 + (_hash_bytes((64, 64), 14) >> 2))
+    rm[..., 1] = 0
+    t_rm = sc.add_texture(rm, abi.TEX_RG8)
+    nrm = np.zeros((64, 64, 4), dtype=np.uint8)
+    nrm[..., 0] = np.where((xx % 16) < 1, 90, np.where((xx % 16) == 1, 166, 128))
+    nrm[..., 1] = np.where((yy % 16) < 1, 90, np.where((yy % 16) == 1, 166, 128))
+    nrm[..., 2] = 240; nrm[..., 3] = 255
+    t_nrm = sc.add_texture(nrm, abi.TEX_RGBA8)
+    banner = np.zeros((64, 32, 4), dtype=np.uint8)
+    by, bx = np.mgrid[0:64, 0:32]
+    banner[..., 0] = 150 + 60 * ((by // 8) % 2); banner[..., 1] = 30; banner[..., 2] = 40
+    banner[..., 3] = np.where((by > 52) & (((bx // 4) % 2) == 0), 0, 255)   # a fringed lower edge: alpha cut-outs
+    t_banner = sc.add_texture(banner, abi.TEX_RGBA8_SRGB)
+    # --- geometry ---
+    quad = sc.add_mesh(plane(1.0))
+    box = sc.add_mesh(cube(1.0))
+    col = sc.add_mesh(sphere(0.5, 48, 64))      # 6144 triangles, stretched into a column
+    orb = sc.add_mesh(sphere(0.5, 24, 32))
+    L, Wd, Hh = 40.0, 14.0, 10.0
+    stone = Material(name="stone", base_texture=t_tiles, rm_texture=t_rm, normal_texture=t_nrm, roughness=1.0, metallic=1.0)
+    plaster = Material(name="plaster", base_color=(0.75, 0.7, 0.62, 1.0), roughness=0.9)
+    sc.add_instance(quad, Transform(scale=(Wd, 1, L)), [stone])                                                   # floor
+    sc.add_instance(box, Transform(translation=(-Wd / 2 - 0.25, Hh / 2, 0), scale=(0.5, Hh, L)), [plaster])        # side walls
+    sc.add_instance(box, Transform(translation=(Wd / 2 + 0.25, Hh / 2, 0), scale=(0.5, Hh, L)), [plaster])
+    sc.add_instance(box, Transform(translation=(0, Hh / 2, -L / 2 - 0.25), scale=(Wd + 1, Hh, 0.5)), [plaster])    # back wall
+    for side in (-1, 1):                                                                                           # roof beams: the sky shows between them
+        for k in range(8):
+            sc.add_instance(box, Transform(translation=(side * Wd / 4, Hh + 0.2, -L / 2 + (k + 0.5) * L / 8), scale=(Wd / 2 - 1.5, 0.4, 1.2)), [plaster])
+    for i in range(columns):
+        for side in (-1, 1):
+            h = _pcg4d((i, side + 2, 5, 0))
+            u = [(c >> 8) / float(1 << 24) for c in h]
+            z = -L / 2 + (i + 0.5) * L / columns
+            kind = h[3] % 4
+            if kind == 0:
+                m = Material(name="marble", base_color=(0.85, 0.83, 0.8, 1.0), roughness=0.35, clearcoat=0.6)
+            elif kind == 1:
+                m = Material(name="bronze", base_color=(0.7, 0.45, 0.2, 1.0), roughness=0.25 + 0.3 * u[0], metallic=1.0, anisotropy=0.4)
+            elif kind == 2:
+                m = Material(name="painted", base_texture=t_tiles, roughness=0.6)
+            else:
+                m = Material(name="stone column", base_color=(0.6, 0.6, 0.58, 1.0), roughness=0.8)
+            sc.add_instance(col, Transform(translation=(side * (Wd / 2 - 2.0), Hh / 2 - 0.5, z), scale=(1.2, Hh - 1.0, 1.2)), [m])
+        if i % 4 == 1:
+            sc.add_instance(quad, Transform(translation=(0, Hh - 2.5, -L / 2 + (i + 0.5) * L / columns), rotation=(np.pi / 2, 0, 0), scale=(3.0, 1, 4.0)),
+                            [Material(name="banner", base_texture=t_banner, base_texture_has_alpha=True, roughness=0.8)])
+        if i % 5 == 2:
+            sc.add_instance(orb, Transform(translation=(0, 1.0, -L / 2 + (i + 0.5) * L / columns), scale=(2, 2, 2)),
+                            [Material(name="glass orb", base_color=(1, 1, 1, 1), roughness=0.05 + 0.1 * (i % 3), ior=1.5, transmission=1.0)])
+        if i % 5 == 4:
+            sc.add_instance(orb, Transform(translation=(2.5 * (1 if i % 2 else -1), Hh - 1.5, -L / 2 + (i + 0.5) * L / columns), scale=(0.8, 0.8, 0.8)),
+                            [Material(name="lamp", base_color=(0, 0, 0, 1), emission=(1.0, 0.75, 0.45), emission_strength=25.0)])
+    env = sky_environment(env_size[0], env_size[1], sun=(int(env_size[0] * 0.30), int(env_size[1] * 0.18)), sun_radiance=400.0)
+    sy, sx = int(env_size[1] * 0.18), int(env_size[0] * 0.30)
+    r = max(2, env_size[0] // 256)
+    env[sy:sy + r, sx:sx + r, :3] = 400.0       # a sun disc that scales with the map resolution
+    sc.env_texture = sc.add_texture(env, abi.TEX_RGBA32F)
+    sc.set_camera(Camera.with_focal_length(24.0), Transform(translation=(0.5, 2.2, L / 2 - 2.0), target=(0, 3.0, -L / 2), track=True))
+    return sc
+
+
 CONFIGS = {
     # name: (scene factory, width, height, spp, bounces)
     "c1": (lambda: cornell_scene("bench"), 512, 512, 64, 4),
     "c2": (cornell_sphere_scene, 1920, 1080, 256, 8),
     "c3": (field_scene, 1920, 1080, 256, 8),
+    "c5": (atrium_scene, 3840, 2160, 512, 12),
 }

@@ -359,3 +359,58 @@ def test_ingested_gltf_parity(gpu_renderer, tmp_path):
         rc, hc = o.debug_sample(s)
         assert np.array_equal(hg, hc) and _same_bits_or_both_nan(rg, rc)
     assert (hc[0, ..., 0] >= 0).mean() > 0.05 and np.nanmean(rc[..., :3]) > 1e-3 and np.isnan(rc).mean() < 0.01
+
+
+# ---- BASELINE configs[4] (C5) stand-in: the procedural atrium ----------------------------------------------------------
+def test_atrium_c5_small_parity(gpu_renderer):
+    sc = scenes.atrium_scene(env_size=(256, 128), columns=6)
+    p = _start(gpu_renderer, sc, 192, 108, 2, 12)
+    o = oracle_lib.OracleScene(sc, p)
+    assert bytes(gpu_renderer.constants()) == bytes(o.constants())
+    assert gpu_renderer.envAlias().tobytes() == o.envAlias().tobytes()
+    for s in (0, 1):
+        rg, hg = gpu_renderer.debugSample(s)
+        rc, hc = o.debug_sample(s)
+        assert np.array_equal(hg, hc) and _same_bits_or_both_nan(rg, rc)
+    gpu_renderer.render(0)
+    assert _same_bits_or_both_nan(gpu_renderer.readbackAccumulator(), o.render(0, 2))
+
+
+def test_atrium_c5_full_size_properties(gpu_renderer):
+    """3840x2160, 12 bounces, 4096x2048 environment (8.4 M alias entries): size-independent properties."""
+    sc = scenes.atrium_scene()
+    assert sc.triangle_count > 250_000
+    _start(gpu_renderer, sc, 3840, 2160, 2, 12, nonfinite_policy=abi.NONFINITE_ZERO)
+    gpu_renderer.render(0)
+    a = gpu_renderer.readbackAccumulator()
+    assert np.isfinite(a).all() and (a[..., 3] == 1).all() and (a[..., :3] >= 0).all()
+    st = gpu_renderer.stats()
+    assert st.paths == 3840 * 2160 * 2 and st.shadow_rays > st.paths and st.nonfinite_samples < 100
+    al = gpu_renderer.envAlias()
+    # (the mean of pdf is 1.03, not 1: the reference sums the 8.4 M importances in fp32, core/environment.cpp:24-31 — kept)
+    assert len(al) == 4096 * 2048 and abs(float(al["pdf"].astype(np.float64).mean()) - 1.0) < 0.05
+    # halves merge to the whole
+    parts = []
+    for first in (0, 1):
+        _start(gpu_renderer, sc, 3840, 2160, 1, 12, first_sample=first, nonfinite_policy=abi.NONFINITE_ZERO)
+        gpu_renderer.render(0)
+        parts.append(gpu_renderer.readbackAccumulator()[..., :3].astype(np.float64))
+    np.testing.assert_allclose(a[..., :3], 0.5 * (parts[0] + parts[1]), rtol=2e-5, atol=1e-6)
+
+
+def test_axis_parallel_rays_do_not_walk_the_whole_tree(gpu_renderer):
+    """Regression: a direction component of exactly 0 used to give inv = inf and NaN slabs (constraints dropped), so rays
+    towards the top row of a lat-long environment — direction exactly (0, 1, 0) — visited thousands of nodes each."""
+    sc = scenes.atrium_scene(env_size=(64, 32), columns=6)
+    env = sc.textures[sc.env_texture].pixels
+    env[...] = 1e-4
+    env[0, :, :3] = 1000.0   # all the importance in the top row: every environment NEE ray points straight up
+    env[..., 3] = 1.0
+    p = _start(gpu_renderer, sc, 160, 90, 1, 4)
+    gpu_renderer.measureTraversal(0)
+    st = gpu_renderer.stats()
+    assert 1.0 < st.nodes_per_shadow_ray < 60, st.nodes_per_shadow_ray   # (thousands before the fix)
+    o = oracle_lib.OracleScene(sc, p)
+    rg, hg = gpu_renderer.debugSample(0)
+    rc, hc = o.debug_sample(0)
+    assert np.array_equal(hg, hc) and _same_bits_or_both_nan(rg, rc)

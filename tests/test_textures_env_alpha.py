@@ -195,6 +195,19 @@ def test_stage_functions_bit_exact_vs_oracle_textured(kw, integrator):
     assert np.isfinite(ro).all() and ro[..., :3].mean() > 1e-3
 
 
+def test_atrium_c5_class_scene_stage_functions_bit_exact():
+    """BASELINE configs[4] stand-in (scenes.atrium_scene) at toy size: every N3 feature in one scene, 12 bounces."""
+    sc = scenes.atrium_scene(env_size=(64, 32), columns=3)
+    p = make_params(80, 45, 1, 12)
+    o, e = oracle_lib.OracleScene(sc, p), emu_lib.EmuScene(sc, p)
+    assert bytes(o.constants()) == bytes(e.constants()) and o.constants().envLightCount == 1
+    assert [bytes(a) for a in o.lights()] == [bytes(b) for b in e.lights()]
+    ro, ho = o.debug_sample(0)
+    re_, he = e.debug_sample(0)
+    assert np.array_equal(ho, he) and ro.tobytes() == re_.tobytes()
+    assert (ho[0, ..., 0] >= 0).mean() > 0.8 and (ho[6:, ..., 0] >= 0).any()   # enclosed hall: long paths exist
+
+
 def test_bvh_and_brute_force_agree_with_alpha_test():
     """The alpha test is applied to every candidate, so closest-hit selection stays BVH-independent."""
     sc = scenes.textured_scene()
