@@ -414,3 +414,51 @@ def test_axis_parallel_rays_do_not_walk_the_whole_tree(gpu_renderer):
     rg, hg = gpu_renderer.debugSample(0)
     rc, hc = o.debug_sample(0)
     assert np.array_equal(hg, hc) and _same_bits_or_both_nan(rg, rc)
+
+
+# ---- degenerate inputs (the reference's tests have none; these pin OUR defined behaviour and guard against GPU faults) ----
+def _tiny_scene(tris, env=True, extra_instances=0):
+    """tris: list of 3x3 vertex arrays (one mesh, one material)."""
+    sc = scenes.Scene(name="tiny")
+    if tris:
+        v = np.concatenate([np.asarray(t, np.float32) for t in tris])
+        n = np.tile(np.array([[0, 1, 0]], np.float32), (len(v), 1))
+        tg = np.tile(np.array([[1, 0, 0, 1]], np.float32), (len(v), 1))
+        uv = np.zeros((len(v), 2), np.float32)
+        m = sc.add_mesh(scenes._make_mesh(v, n, tg, uv, np.arange(len(v)), np.zeros(len(tris))))
+        for k in range(1 + extra_instances):
+            sc.add_instance(m, scenes.Transform(translation=(0, 0.0, 0)), [scenes.Material(base_color=(0.6, 0.5, 0.4, 1.0))])
+    if env:
+        sc.env_texture = sc.add_texture(scenes.sky_environment(16, 8), abi.TEX_RGBA32F)
+    sc.set_camera(scenes.Camera.with_focal_length(28.0), scenes.Transform(translation=(0, 2, 5), target=(0, 0, 0), track=True))
+    return sc
+
+
+@pytest.mark.parametrize("case", ["empty", "one_triangle", "two_triangles", "zero_area", "coincident_copies", "three_instances_same_place"])
+def test_degenerate_scenes_match_oracle(gpu_renderer, case):
+    quad = [[[-2, 0, -2], [-2, 0, 2], [2, 0, -2]], [[2, 0, -2], [-2, 0, 2], [2, 0, 2]]]
+    if case == "empty":
+        sc = _tiny_scene([])
+    elif case == "one_triangle":
+        sc = _tiny_scene(quad[:1])
+    elif case == "two_triangles":
+        sc = _tiny_scene(quad)
+    elif case == "zero_area":
+        sc = _tiny_scene(quad + [[[0, 1, 0], [0, 1, 0], [0, 1, 0]], [[1, 1, 1], [2, 2, 2], [3, 3, 3]]])  # a point and a line
+    elif case == "coincident_copies":
+        sc = _tiny_scene(quad * 40)               # 80 triangles, 40 exact copies of each: the tie-break decides
+    else:
+        sc = _tiny_scene(quad, extra_instances=2)  # three instances of the same mesh at the same place
+    p = _start(gpu_renderer, sc, 64, 36, 2, 4)
+    o = oracle_lib.OracleScene(sc, p)
+    g, c = gpu_renderer.tracePrimary(0), o.trace_primary(0)
+    assert g.tobytes() == c.tobytes()
+    if case in ("coincident_copies", "three_instances_same_place", "two_triangles"):
+        hit = g["instance"] >= 0
+        assert hit.any() and np.all(g["instance"][hit] == 0) and np.all(g["primitive"][hit] <= 1)  # lowest (instance, primitive) wins ties
+    for s in (0, 1):
+        rg, hg = gpu_renderer.debugSample(s)
+        rc, hc = o.debug_sample(s)
+        assert np.array_equal(hg, hc) and _same_bits_or_both_nan(rg, rc)
+    gpu_renderer.render(0)
+    assert _same_bits_or_both_nan(gpu_renderer.readbackAccumulator(), o.render(0, 2))
