@@ -594,6 +594,13 @@ __global__ void __launch_bounds__(kBlock) k_fold_counters(const BatchCounters* _
   }
 }
 
+// one ShadeRec per flattened triangle, in tris[] order (once per render, after the BVH build)
+__global__ void __launch_bounds__(kBlock) k_shade_records(DeviceScene S, ShadeRec* __restrict__ out) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= S.tri_count) return;
+  out[t] = make_shade_rec(S, S.tris[t]);
+}
+
 // primary-ray records for pt_trace_primary: segment order -> pixel order
 __global__ void __launch_bounds__(kBlock) k_hit_records(DeviceScene S, PathState st, const vec4* __restrict__ hit, Segments seg,
                                                          pt_hit_record* __restrict__ out) {
@@ -662,6 +669,9 @@ void launch_postprocess(hipStream_t s, const vec4* acc, uint32_t* rgba8, uint32_
 }
 void launch_fold_counters(hipStream_t s, const BatchCounters* ctr, Totals* tot, Segments seg, bool counted) {
   hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(kBlock), 0, s, ctr, tot, seg, counted ? 1u : 0u);
+}
+void launch_shade_records(hipStream_t s, const DeviceScene& S, ShadeRec* out) {
+  if (S.tri_count) hipLaunchKernelGGL(k_shade_records, dim3((S.tri_count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, S, out);
 }
 void launch_hit_records(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, const vec4* hit, Segments seg,
                         pt_hit_record* out) {

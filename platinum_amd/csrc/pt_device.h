@@ -40,6 +40,11 @@ struct alignas(16) TriRec {
 };
 static_assert(sizeof(TriRec) == 48, "TriRec");
 
+// What shading needs to know about a hit triangle, resolved once per render (k_shade_records) and indexed like tris[]:
+// absolute vertex indices and the absolute index of its MaterialGPU.  Without it every shaded hit walks
+// tris -> instances -> meshes -> indices / slots -> vertices / materials: five dependent loads instead of two.
+struct alignas(16) ShadeRec { uint32_t v[3]; uint32_t material; };
+
 // 4-wide BVH node with child boxes quantised to 8 bits per coordinate relative to the node's own box, 64 B =
 // 4 x dwordx4 (one half of a 128-B L2 line).  The traversal kernels are bound by vector-L1 lookups,
 // so the node packs four children into the bytes a binary node needed for two.
@@ -98,6 +103,7 @@ struct DeviceScene {
   const pt_area_light* lights;
   const BvhNode* nodes;
   const TriRec* tris;
+  const ShadeRec* shade_recs;  // tri_count records, same order as tris[]
   uint32_t tri_count;
   uint32_t root_ref;       // kLeafBit|0 for a single-triangle scene, 0 otherwise, kInvalidRef when empty
   const HaltonEntry* halton;

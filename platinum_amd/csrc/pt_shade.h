@@ -42,6 +42,17 @@ PT_HD vec3 ld3(const pt_float3& v) { return v3(v.x, v.y, v.z); }
 // defs.metal:27-30
 PT_HD vec3 interpolate3(vec3 a0, vec3 a1, vec3 a2, float u, float v) { return ((1.0f - u - v) * a0 + u * a1) + v * a2; }
 
+// getIntersectionData's table walk (kernel.metal:118-141), done once per triangle instead of once per hit
+PT_HD ShadeRec make_shade_rec(const DeviceScene& S, const TriRec& tr) {
+  const InstanceInfo& inst = S.instances[tr.inst];
+  const MeshInfo mesh = S.meshes[inst.mesh];
+  const uint32_t* __restrict__ idx = &S.indices[3 * (size_t)(mesh.tri_base + tr.prim)];
+  ShadeRec r;
+  r.v[0] = mesh.vertex_base + idx[0]; r.v[1] = mesh.vertex_base + idx[1]; r.v[2] = mesh.vertex_base + idx[2];
+  r.material = inst.material_base + S.slots[mesh.tri_base + tr.prim];
+  return r;
+}
+
 // ---- raygen -----------------------------------------------------------------------------------------------------
 struct RayGenOut { vec3 o, d; uint32_t offset, dim; };
 
@@ -173,15 +184,11 @@ PT_HD ShadeOut stage_shade(const DeviceScene& S, const ShadeIn& in) {
   Halton halton{S.halton, in.offset, in.dim};
 
   // ---- Resources::getIntersectionData (kernel.metal:118-188) ----
-  const TriRec* __restrict__ trp = &S.tris[in.tri];
-  const uint32_t instanceIdx = trp->inst;
-  const uint32_t primitiveId = trp->prim;
+  const uint32_t instanceIdx = S.tris[in.tri].inst;
+  const ShadeRec rec = S.shade_recs[in.tri];  // (vertexResources / primitiveResources / instanceResources lookups, resolved per render)
   const InstanceInfo inst = S.instances[instanceIdx];
-  const MeshInfo mesh = S.meshes[inst.mesh];
-  const uint32_t* __restrict__ idx = &S.indices[3 * (size_t)(mesh.tri_base + primitiveId)];
-  const uint32_t i0 = mesh.vertex_base + idx[0], i1 = mesh.vertex_base + idx[1], i2 = mesh.vertex_base + idx[2];
-  const uint32_t materialSlot = S.slots[mesh.tri_base + primitiveId];
-  const pt_material_gpu material = S.materials[inst.material_base + materialSlot];
+  const uint32_t i0 = rec.v[0], i1 = rec.v[1], i2 = rec.v[2];
+  const pt_material_gpu material = S.materials[rec.material];
 
   const vec3 p0 = ld3(S.positions[i0]), p1 = ld3(S.positions[i1]), p2 = ld3(S.positions[i2]);
   const pt_vertex_data vd0 = S.vdata[i0], vd1 = S.vdata[i1], vd2 = S.vdata[i2];

@@ -95,6 +95,7 @@ struct pt_renderer {
   DevBuf<pt_area_light> lights_d;
   std::vector<pt_area_light> lights;
   DevBuf<DeviceScene> scene_d;
+  DevBuf<ShadeRec> shade_recs;
   DevBuf<vec4> tex_pixels;            // all textures decoded to linear float4 (host_scene.h decode_textures)
   DevBuf<TexInfo> textures;
   DevBuf<pt_alias_entry> env_alias_d;
@@ -141,7 +142,7 @@ struct pt_renderer {
 
   void free_scene() {
     positions.release(); vdata.release(); indices.release(); slots.release(); meshes.release(); instances.release();
-    materials.release(); lights_d.release(); tex_pixels.release(); textures.release(); env_alias_d.release(); scene_d.release();
+    materials.release(); lights_d.release(); tex_pixels.release(); textures.release(); env_alias_d.release(); scene_d.release(); shade_recs.release();
     if (bvh.nodes) (void)hipFree(bvh.nodes);
     if (bvh.tris) (void)hipFree(bvh.tris);
     bvh = LbvhResult{};
@@ -446,6 +447,9 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
     S.tris = r->bvh.tris;
     S.root_ref = r->bvh.root_ref;
   }
+  PT_HIP(r->shade_recs.alloc(r->tri_count));
+  S.shade_recs = r->shade_recs.p;
+  launch_shade_records(r->stream, S, r->shade_recs.p);
   PT_HIP(r->scene_d.upload(std::vector<DeviceScene>(1, S)));  // k_shade reads the table from memory (scalar loads)
 
   // ---- wavefront buffers ----

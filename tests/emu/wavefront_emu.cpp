@@ -22,6 +22,7 @@ struct Emu {
   std::vector<float> lut;
   std::vector<HaltonEntry> halton;
   std::vector<TriRec> tris;
+  std::vector<ShadeRec> shade_recs;
   std::vector<BvhNode> nodes;
   DeviceScene S{};
   pt_render_params params{};
@@ -127,6 +128,9 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
   S.meshes = e->hs.meshes.data(); S.instances = e->hs.instances.data(); S.materials = e->hs.materials.data();
   S.lights = e->hs.lights.data(); S.nodes = e->nodes.data(); S.tris = e->tris.data(); S.tri_count = (uint32_t)e->tris.size();
   S.root_ref = root; S.halton = e->halton.data();
+  e->shade_recs.resize(e->tris.size());
+  for (size_t i = 0; i < e->tris.size(); i++) e->shade_recs[i] = make_shade_rec(S, e->tris[i]);
+  S.shade_recs = e->shade_recs.data();
   Lut* ls[6] = {&S.luts.E, &S.luts.Eavg, &S.luts.EMs, &S.luts.EavgMs, &S.luts.ETransIn, &S.luts.ETransOut};
   for (int i = 0; i < 6; i++) { ls[i]->w = hdr[4 * i]; ls[i]->h = hdr[4 * i + 1]; ls[i]->depth = hdr[4 * i + 2]; ls[i]->d = e->lut.data() + hdr[4 * i + 3]; }
   S.camera = e->hs.constants.camera; S.idt = e->hs.idt; S.width = p->width; S.height = p->height;
