@@ -242,7 +242,7 @@ __device__ __forceinline__ void wave_traverse(const DeviceScene& S, TravState& t
 
 // ---- closest hit ---------------------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments seg,
+__global__ void __launch_bounds__(kBlock, PT_TRACE_WAVES) k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments seg,
                                                            uint32_t cur, BatchCounters* __restrict__ ctr, uint32_t bounce,
                                                            uint32_t* __restrict__ spill, int32_t* __restrict__ hitlog,
                                                            uint32_t log_stride) {
@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(const DeviceSc
 
 // ---- shadow (any hit) --------------------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments seg,
+__global__ void __launch_bounds__(kBlock, PT_TRACE_WAVES) k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments seg,
                                                           BatchCounters* __restrict__ ctr, uint32_t bounce,
                                                           uint32_t* __restrict__ spill) {
   __shared__ uint32_t lds_stack[kLdsStack + 1][kBlock];

@@ -60,11 +60,23 @@ PT_HD float slab_entry(const float lo[3], const float hi[3], vec3 o, vec3 inv, f
 // Per-lane traversal stack: the first kLdsStack entries live in LDS ([depth][lane], bank = lane; row kLdsStack is a
 // scratch row that absorbs the writes of the branch-free push), the rest spill to a per-thread HBM slab (only
 // pathological trees get there).
-constexpr int kLdsStack = 16;
-constexpr int kSpillStack = 80;  // total 96 entries: up to 3 pushes per level of a 4-wide tree that is <= 48 levels deep
+// Occupancy of the trace kernels: 7 blocks of 256 threads per CU = 7 waves per SIMD need <= 72 VGPRs and <= 22.8 KB of LDS
+// per block: (13 + 1) stack rows + (7 + 1) leaf-queue rows of 1 KB.  Measured against 6 waves (16 + 8 rows): closest-hit
+// on C3 10 % faster, C2 unchanged; 8 waves (64 VGPRs, 12 + 6 rows) spills registers and is slower.
+#ifndef PT_TRACE_WAVES
+#define PT_TRACE_WAVES 7
+#endif
+#ifndef PT_LDS_STACK
+#define PT_LDS_STACK 13
+#endif
+#ifndef PT_PEND_LEAVES
+#define PT_PEND_LEAVES 7
+#endif
+constexpr int kLdsStack = PT_LDS_STACK;
+constexpr int kSpillStack = 96 - PT_LDS_STACK;  // total 96 entries: up to 3 pushes per level of a 4-wide tree that is <= 48 levels deep
                                  // (binary LBVH depth <= 95 over 63-bit codes + index tie-break, halved by the collapse)
 
-constexpr int kPendLeaves = 8;   // per-lane queue of leaf candidates awaiting their triangle test (LDS, [slot][lane])
+constexpr int kPendLeaves = PT_PEND_LEAVES;   // per-lane queue of leaf candidates awaiting their triangle test (LDS, [slot][lane])
 
 struct TraversalStack {
   uint32_t* lds;     // &lds_stack[0][lane_in_block]

@@ -118,6 +118,7 @@ struct pt_renderer {
   pt_post_options post{};
   pt_tonemap_options tonemap{};
   DevBuf<uint32_t> render_target;  // RGBA8 (renderer_pt.cpp:832-835)
+  uint32_t trace_grid = 0, trace_blocks_per_cu = PT_TRACE_WAVES;
   uint32_t nwaves = 0, seg_cap = 0, blocks_per_cu = 6, tile_contiguous = 0, refill_threshold = 48;
   DevBuf<BatchCounters> ctr;
   DevBuf<Totals> totals;
@@ -196,7 +197,7 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
   for (uint32_t b = 0; b < S.max_bounces; b++) {
     {
       ScopedTimer t(r, K_CLOSEST);
-      launch_trace_closest(s, r->grid, S, r->path_state(cur), r->hit.p, seg, (uint32_t)cur, ctr, b, r->spill.p, hitlog, S.width * S.height, count);
+      launch_trace_closest(s, r->trace_grid, S, r->path_state(cur), r->hit.p, seg, (uint32_t)cur, ctr, b, r->spill.p, hitlog, S.width * S.height, count);
     }
     {
       ScopedTimer t(r, K_SHADE);
@@ -206,7 +207,7 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
     }
     if (mis) {
       ScopedTimer t(r, K_SHADOW);
-      launch_trace_shadow(s, r->grid, S, r->shadow_queue(), r->Lbuf.p, seg, ctr, b, r->spill.p, count);
+      launch_trace_shadow(s, r->trace_grid, S, r->shadow_queue(), r->Lbuf.p, seg, ctr, b, r->spill.p, count);
     }
     cur ^= 1;
   }
@@ -310,6 +311,7 @@ int pt_create(const pt_create_info* info, pt_renderer** out) {
   if (const char* e = getenv("PTAMD_REFILL")) r->refill_threshold = (uint32_t)atoi(e);
   if (const char* e = getenv("PTAMD_TILE_CONTIGUOUS")) r->tile_contiguous = (uint32_t)atoi(e);  // tuning knobs
   if (const char* e = getenv("PTAMD_BLOCKS_PER_CU")) r->blocks_per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));
+  if (const char* e = getenv("PTAMD_TRACE_BLOCKS_PER_CU")) r->trace_blocks_per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, r->device) == hipSuccess) r->num_cu = prop.multiProcessorCount;
   int rc = PT_OK;
@@ -469,6 +471,8 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
   // The grid must be fully RESIDENT for the trace kernels (a wave that starts late would serialise its whole segment
   // behind the others): 6 blocks of 256 threads per CU fit their 16 KiB LDS slab, <= 80 VGPRs and ~96 SGPRs.
   r->grid = (uint32_t)r->num_cu * r->blocks_per_cu;
+  // the trace kernels claim chunks from a table, so their grid is free: as many blocks as their LDS / VGPR budget keeps resident
+  r->trace_grid = (uint32_t)r->num_cu * r->trace_blocks_per_cu;
   r->nwaves = r->grid * (kBlock / 64);
   {
     const uint64_t tiles = (uint64_t)((p->width + 7) / 8) * ((p->height + 7) / 8);
@@ -488,7 +492,7 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
   PT_HIP(r->seg_shadow.alloc(r->nwaves));
   PT_HIP(r->wave_stats.alloc(r->nwaves));
   for (int k = 0; k < 2; k++) PT_HIP(r->chunk_table[k].alloc(r->capacity / 64));
-  PT_HIP(r->spill.alloc((size_t)r->grid * kBlock * kSpillStack));  // per-thread HBM stack slab behind the LDS stack
+  PT_HIP(r->spill.alloc((size_t)r->trace_grid * kBlock * kSpillStack));  // per-thread HBM stack slab behind the LDS stack
   PT_HIP(hipMemsetAsync(r->wave_stats.p, 0, sizeof(WaveStats) * r->nwaves, r->stream));
   if (p->external_accumulator) {
     r->acc = (vec4*)p->external_accumulator;
@@ -682,7 +686,7 @@ int pt_trace_primary(pt_renderer* r, uint32_t sample_idx, pt_hit_record* out) {
   PT_HIP(hipMemsetAsync(r->ctr.p, 0, sizeof(BatchCounters), s));
   launch_raygen(s, r->grid, r->S, r->path_state(0), r->Lbuf.p, r->segments(), r->ctr.p, sample_idx, 1);
   launch_chunk_tables(s, r->segments(), 0, r->ctr.p, 0, 0, false);
-  launch_trace_closest(s, r->grid, r->S, r->path_state(0), r->hit.p, r->segments(), 0, r->ctr.p, 0, r->spill.p, nullptr, npix, false);
+  launch_trace_closest(s, r->trace_grid, r->S, r->path_state(0), r->hit.p, r->segments(), 0, r->ctr.p, 0, r->spill.p, nullptr, npix, false);
   launch_hit_records(s, r->grid, r->S, r->path_state(0), r->hit.p, r->segments(), rec.p);
   launch_fold_counters(s, r->ctr.p, r->totals.p + 1, r->segments(), false);  // clears the per-wave statistics (scratch slot)
   PT_HIP(hipGetLastError());
