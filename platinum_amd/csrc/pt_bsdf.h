@@ -180,15 +180,31 @@ struct BSDF {
   bool ms;  // RendererFlags_MultiscatterGGX
   static constexpr float kClearcoatIor = 1.5f;  // defs.metal:345
 
-  PT_HD BSDF(const ShadingContext& c, int rendererFlags, const LutSet& l)
+  // The energy-table terms that depend only on the outgoing direction and the material: the reference evaluates them
+  // again in every lobe of sample() and of the NEE eval() (bsdf.metal:291-326, defs.metal:349-361); a shaded hit uses ONE
+  // wo for both calls, so they are looked up once here — same functions, same arguments, same bits.
+  float cE_wo = 0.0f, cE_avg = 0.0f, cEms_wo = 0.0f, cEms_avg = 0.0f;
+
+  PT_HD BSDF(const ShadingContext& c, int rendererFlags, const LutSet& l, vec3 wo)
       : ctx(c), luts(l), ggx(make_ggx(c.roughness, c.anisotropy)), ggxCoat(make_ggx(c.clearcoatRoughness)),
-        ms((rendererFlags & PT_FLAG_MULTISCATTER_GGX) != 0) {}
+        ms((rendererFlags & PT_FLAG_MULTISCATTER_GGX) != 0) {
+    const float m = c.metallic, t = c.transmission;
+    // the opaque lobe can be SAMPLED with probability (1-m)(1-t) and is EVALUATED with weight (1-m)(1-(1-m)t)
+    const bool opaque_lobe = (1.0f - m) * (1.0f - t) > 0.0f || (1.0f - m) * (1.0f - (1.0f - m) * t) > 0.0f;
+    if (opaque_lobe || (ms && m > 0.0f)) cE_wo = lut2(luts.E, wo.z, ctx.roughness);
+    if (ms && (opaque_lobe || m > 0.0f)) cE_avg = lut1(luts.Eavg, ctx.roughness);
+    if (opaque_lobe) {
+      const float iorParam = (ctx.ior - 1.0f) / ctx.ior;
+      cEms_wo = lut3(luts.EMs, wo.z, ctx.roughness, iorParam);
+      cEms_avg = lut2(luts.EavgMs, iorParam, ctx.roughness);
+    }
+  }
 
   // defs.metal:349-361 — the E / Eavg part is shared by the float and float3 instantiations
   PT_HD void multiscatter_terms(vec3 wo, vec3 wi, float* brdf_ms, float* E_avg) const {
-    const float E_wo = lut2(luts.E, wo.z, ctx.roughness);
+    const float E_wo = cE_wo;
     const float E_wi = lut2(luts.E, wi.z, ctx.roughness);
-    *E_avg = lut1(luts.Eavg, ctx.roughness);
+    *E_avg = cE_avg;
     *brdf_ms = (1.0f - E_wo) * (1.0f - E_wi) / (kPi * (1.0f - *E_avg));
   }
   PT_HD float multiscatter(vec3 wo, vec3 wi, float F_avg) const {
@@ -213,15 +229,14 @@ struct BSDF {
   }
   PT_HD float diffuseFactor(vec3 wo, vec3 wi) const {  // bsdf.metal:291-305
     const float iorParam = (ctx.ior - 1.0f) / ctx.ior;
-    const float E_ms_wo = lut3(luts.EMs, wo.z, ctx.roughness, iorParam);
+    const float E_ms_wo = cEms_wo;
     const float E_ms_wi = lut3(luts.EMs, wi.z, ctx.roughness, iorParam);
-    const float E_ms_avg = lut2(luts.EavgMs, iorParam, ctx.roughness);
+    const float E_ms_avg = cEms_avg;
     return (1.0f - E_ms_wo) * (1.0f - E_ms_wi) / (kPi * (1.0f - E_ms_avg));
   }
   PT_HD float opaqueDielectricFactor(vec3 wo, float F_avg) const {  // bsdf.metal:311-326
-    const float iorParam = (ctx.ior - 1.0f) / ctx.ior;
-    const float E_wo = lut2(luts.E, wo.z, ctx.roughness);
-    const float E_ms_wo = lut3(luts.EMs, wo.z, ctx.roughness, iorParam);
+    const float E_wo = cE_wo;
+    const float E_ms_wo = cEms_wo;
     const float fresnel_ms = F_avg * F_avg * E_wo / (1.0f - F_avg * (1.0f - E_wo));
     return F_avg * E_ms_wo + fresnel_ms * (1.0f - E_ms_wo);
   }
