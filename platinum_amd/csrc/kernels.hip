@@ -214,10 +214,16 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DeviceScene S, PathState st, 
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void wave_traverse(const DeviceScene& S, TravState& ts, TraversalCount* tc) {
 #ifdef PT_WAVE_COUNT
+  // instrumentation build (tools/sweep_variants.sh): nodes += lanes holding a ray in this iteration, tris += lanes of
+  // them that cannot visit a node (PT_WAVE_COUNT == 1: draining = node stack exhausted, leaves queued; == 2: queue full)
   TraversalCount dummy;
-  const bool first = (int)__builtin_ctzll(__ballot(1)) == (int)(threadIdx.x & 63);
   const bool donode = ts.cur != kInvalidRef && ts.st.npend <= kPendLeaves - 4;
-  if (COUNT && first && __ballot(donode) != 0) tc->nodes += 64;
+  if (COUNT) {
+    tc->nodes += 1;
+    if (PT_WAVE_COUNT == 1 && ts.cur == kInvalidRef && ts.st.npend > 0) tc->tris += 1;
+    if (PT_WAVE_COUNT == 2 && ts.cur != kInvalidRef && !donode) tc->tris += 1;
+    if (PT_WAVE_COUNT == 3) { const bool first = (int)__builtin_ctzll(__ballot(1)) == (int)(threadIdx.x & 63); if (first) tc->tris += 64; }
+  }
   if (donode) trav_node<false>(S, ts, &dummy);
 #else
   if (ts.cur != kInvalidRef && ts.st.npend <= kPendLeaves - 4) trav_node<COUNT>(S, ts, tc);
@@ -229,7 +235,6 @@ __device__ __forceinline__ void wave_traverse(const DeviceScene& S, TravState& t
   if (mp == 0) return;
   const bool go = PT_GO_DEN * __popcll(mp) >= PT_GO_NUM * __popcll(__ballot(1)) || PT_FULL_LANES * __popcll(__ballot(ts.st.npend > kPendLeaves - 4)) >= 64 || __ballot(advancing) == 0;
 #ifdef PT_WAVE_COUNT
-  if (COUNT && first && go) tc->tris += 64;
   if (go && pending) {
     if (trav_pending_leaf<ANY, false>(S, ts, &dummy)) { ts.cur = kInvalidRef; ts.st.npend = 0; ts.st.sp = 0; }
   }
