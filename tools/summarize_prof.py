@@ -19,7 +19,7 @@ def short(name):
     if "rocprim" in name: return "rocprim_radix_sort"
     return name[:40]
 
-stats = glob.glob(os.path.join(prof_dir, f"{wl}_trace", "*", "*_kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(prof_dir, f"{wl}_trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)  # newest run
 shutil.copy(stats, os.path.join(out_dir, f"{tag}_{wl}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 summary = {}
@@ -32,7 +32,7 @@ def counter(kind):
     f = glob.glob(os.path.join(prof_dir, f"{wl}_{kind}", "*", "*_counter_collection.csv"))
     acc = defaultdict(lambda: [0, 0.0])
     if not f: return acc
-    for r in csv.DictReader(open(f[0])):
+    for r in csv.DictReader(open(max(f, key=os.path.getmtime))):
         k = short(r["Kernel_Name"])
         acc[k][0] += 1; acc[k][1] += float(r["Counter_Value"])
     return acc
