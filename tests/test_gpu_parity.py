@@ -462,3 +462,15 @@ def test_degenerate_scenes_match_oracle(gpu_renderer, case):
         assert np.array_equal(hg, hc) and _same_bits_or_both_nan(rg, rc)
     gpu_renderer.render(0)
     assert _same_bits_or_both_nan(gpu_renderer.readbackAccumulator(), o.render(0, 2))
+
+
+def test_render_scene_tool_end_to_end(tmp_path):
+    """tools/render_scene.py: scene.json -> ingestion -> GMoN render -> fused post-process -> PNG, in a child process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "mini.png"
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "render_scene.py"), os.path.join(root, "tests", "golden", "scene_fixture", "mini.json"),
+                        str(out), "--size", "96", "54", "--spp", "16", "--gmon", "4"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    data = out.read_bytes()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n" and len(data) > 1000 and "Msamples/s" in p.stdout
