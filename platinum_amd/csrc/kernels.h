@@ -54,9 +54,11 @@ struct LbvhResult {
   uint32_t root_ref = kInvalidRef;
   uint32_t node_count = 0;    // 4-wide nodes emitted
   uint32_t max_depth = 0;     // of the binary tree
+  uint32_t depth4 = 0;        // levels of the 4-wide tree (the traversal stack needs <= 3 entries per level)
 };
 // Flattens the instanced scene to world-space triangles and builds the BVH entirely on the device.
 // `S` needs positions / indices / meshes / instances filled in. Returns hipSuccess or the failing HIP error.
-hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_count, uint32_t tri_count, LbvhResult* out);
+hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_count, uint32_t tri_count, uint32_t stack_capacity,
+                      LbvhResult* out);
 
 }  // namespace pt

@@ -242,11 +242,64 @@ __global__ void __launch_bounds__(256) k_emit(int n, const uint2* __restrict__ c
   atomicAdd(emitted, 1u);
 }
 
+// Surface-area-guided collapse, one tree level per launch: the 4-wide node rooted at binary node i starts from i's two
+// children and keeps opening the internal child with the largest surface area until four slots are used (the even-depth
+// rule above opens both children blindly).  Internal children are appended to the next level's queue.  On Morton trees
+// this visits 5-13 % fewer nodes per ray (measured with the host build of the same traversal: C2 7.73 -> 7.37, a 259 k
+// triangle field 11.3 -> 10.5, the atrium 17.0 -> 14.8).
+__global__ void __launch_bounds__(256) k_emit_sah(uint32_t n_in, const uint32_t* __restrict__ q_in, uint32_t* __restrict__ q_out,
+                                                   uint32_t* __restrict__ n_out, const uint2* __restrict__ children,
+                                                   const Box* __restrict__ leaf_boxes, const uint32_t* __restrict__ order,
+                                                   const Box* __restrict__ node_boxes, BvhNode* __restrict__ nodes,
+                                                   uint32_t* __restrict__ emitted) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_in) return;
+  const uint32_t i = q_in[t];
+  auto box_of = [&](uint32_t ref) { return (ref & kLeafBit) ? leaf_boxes[order[ref & ~kLeafBit]] : node_boxes[ref]; };
+  auto half_area = [](const Box& b) {
+    const float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
+    return x * y + y * z + z * x;
+  };
+  const uint2 ch = children[i];
+  uint32_t refs[4] = {ch.x, ch.y, kInvalidRef, kInvalidRef};
+  Box bx[4];
+  bx[0] = box_of(refs[0]); bx[1] = box_of(refs[1]);
+  int count = 2;
+  while (count < 4) {
+    int best = -1;
+    float best_area = -1.0f;
+    for (int k = 0; k < count; k++)
+      if (!(refs[k] & kLeafBit)) { const float a = half_area(bx[k]); if (a > best_area) { best_area = a; best = k; } }
+    if (best < 0) break;
+    const uint2 g = children[refs[best]];
+    refs[best] = g.x; bx[best] = box_of(g.x);
+    refs[count] = g.y; bx[count] = box_of(g.y);
+    count++;
+  }
+  Box3 boxes[4];
+  for (int k = 0; k < count; k++) {
+    Box3 e;
+    for (int a = 0; a < 3; a++) { e.lo[a] = bx[k].lo[a]; e.hi[a] = bx[k].hi[a]; }
+    boxes[k] = inflate_box(e);
+  }
+  nodes[i] = quantize_node4(boxes, refs, count);
+  for (int k = 0; k < count; k++)
+    if (!(refs[k] & kLeafBit)) q_out[atomicAdd(n_out, 1u)] = refs[k];
+  atomicAdd(emitted, 1u);
+}
+__global__ void __launch_bounds__(256) k_reorder_tris(int n, const uint32_t* __restrict__ order, const TriRec* __restrict__ tris_in,
+                                                       TriRec* __restrict__ tris_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) tris_out[i] = tris_in[order[i]];
+}
+__global__ void k_seed_queue(uint32_t* q, uint32_t* counters) { q[0] = 0u; counters[0] = 0u; counters[1] = 0u; }
+
 #define LB_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = e_; goto done; } } while (0)
 
 }  // namespace
 
-hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_count, uint32_t tri_count, LbvhResult* out) {
+hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_count, uint32_t tri_count, uint32_t stack_capacity,
+                      LbvhResult* out) {
   *out = LbvhResult{};
   if (tri_count == 0) return hipSuccess;
   hipError_t err = hipSuccess;
@@ -262,8 +315,8 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
   LB_CHECK(hipMalloc(&out->tris, sizeof(TriRec) * (size_t)n));
   LB_CHECK(hipMalloc(&leaf_boxes, sizeof(Box) * (size_t)n));
   LB_CHECK(hipMalloc(&bounds, sizeof(int) * 8));
-  LB_CHECK(hipMalloc(&max_depth, 2 * sizeof(uint32_t)));  // [0] max binary depth, [1] emitted 4-wide nodes
-  LB_CHECK(hipMemsetAsync(max_depth, 0, 2 * sizeof(uint32_t), s));
+  LB_CHECK(hipMalloc(&max_depth, 4 * sizeof(uint32_t)));  // [0] max binary depth, [1] emitted 4-wide nodes (fallback), [2..3] BFS counters
+  LB_CHECK(hipMemsetAsync(max_depth, 0, 4 * sizeof(uint32_t), s));
   hipLaunchKernelGGL(k_flatten, dim3(blocks), dim3(256), 0, s, S, instance_count, n, tris_tmp, leaf_boxes);
 
   if (n == 1) {
@@ -271,6 +324,7 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
     out->root_ref = kLeafBit | 0u;
     out->node_count = 0;
     out->max_depth = 1;
+    out->depth4 = 0;
     LB_CHECK(hipStreamSynchronize(s));
     goto done;
   }
@@ -298,14 +352,47 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
   hipLaunchKernelGGL(k_karras, dim3(blocks), dim3(256), 0, s, keys_b, (int)n, children, parent_int, parent_leaf);
   hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, s, (int)n, children, parent_int, parent_leaf, leaf_boxes, vals_b,
                      node_boxes, flags, max_depth);
-  hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, s, (int)n, children, parent_int, leaf_boxes, vals_b, node_boxes, tris_tmp,
-                     out->nodes, out->tris, max_depth + 1);
-  LB_CHECK(hipGetLastError());
-  LB_CHECK(hipMemcpyAsync(depth_h, max_depth, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  LB_CHECK(hipMemcpyAsync(depth_h, max_depth, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   LB_CHECK(hipStreamSynchronize(s));
-  out->root_ref = 0;
-  out->node_count = depth_h[1];
   out->max_depth = depth_h[0];
+  {
+    // level-synchronous SAH collapse; queues live in the sort's scratch (vals_a: 4n bytes, keys_a: 8n bytes)
+    uint32_t* q_in = vals_a;
+    uint32_t* q_out = reinterpret_cast<uint32_t*>(keys_a);
+    uint32_t* counters = max_depth + 2;  // [0] next level's size, [1] nodes emitted
+    hipLaunchKernelGGL(k_seed_queue, dim3(1), dim3(1), 0, s, q_in, counters);
+    uint32_t n_in = 1, levels = 0, emitted = 0;
+    bool too_deep = false;
+    while (n_in > 0) {
+      if ((levels + 1) * 3 > stack_capacity) { too_deep = true; break; }
+      hipLaunchKernelGGL(k_emit_sah, dim3((n_in + 255) / 256), dim3(256), 0, s, n_in, q_in, q_out, counters, children, leaf_boxes, vals_b,
+                         node_boxes, out->nodes, counters + 1);
+      uint32_t h[2];
+      LB_CHECK(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, s));
+      LB_CHECK(hipMemsetAsync(counters, 0, sizeof(uint32_t), s));
+      LB_CHECK(hipStreamSynchronize(s));
+      n_in = h[0]; emitted = h[1];
+      std::swap(q_in, q_out);
+      levels++;
+    }
+    if (too_deep) {
+      // pathological tree: the even-depth collapse bounds the 4-wide depth by half the binary depth
+      LB_CHECK(hipMemsetAsync(max_depth + 1, 0, sizeof(uint32_t), s));
+      hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, s, (int)n, children, parent_int, leaf_boxes, vals_b, node_boxes, tris_tmp,
+                         out->nodes, out->tris, max_depth + 1);
+      LB_CHECK(hipMemcpyAsync(depth_h, max_depth, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      LB_CHECK(hipStreamSynchronize(s));
+      emitted = depth_h[1];
+      levels = (out->max_depth + 1) / 2;
+    } else {
+      hipLaunchKernelGGL(k_reorder_tris, dim3(blocks), dim3(256), 0, s, (int)n, vals_b, tris_tmp, out->tris);
+    }
+    LB_CHECK(hipGetLastError());
+    LB_CHECK(hipStreamSynchronize(s));
+    out->root_ref = 0;
+    out->node_count = emitted;
+    out->depth4 = levels;
+  }
 
 done:
   (void)hipFree(tris_tmp); (void)hipFree(leaf_boxes); (void)hipFree(node_boxes); (void)hipFree(keys_a); (void)hipFree(keys_b); (void)hipFree(vals_a);

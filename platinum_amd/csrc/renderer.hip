@@ -431,7 +431,7 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
     PT_HIP(hipEventCreate(&e0));
     PT_HIP(hipEventCreate(&e1));
     PT_HIP(hipEventRecord(e0, r->stream));
-    hipError_t be = build_lbvh(r->stream, S, r->instance_count, r->tri_count, &r->bvh);
+    hipError_t be = build_lbvh(r->stream, S, r->instance_count, r->tri_count, (uint32_t)(kLdsStack + kSpillStack), &r->bvh);
     if (be != hipSuccess) {
       (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
       return fail(be == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP, std::string("LBVH build failed: ") + hipGetErrorString(be));
@@ -443,7 +443,7 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
     r->bvh_ms = ms;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     // traversal stack: <= 3 pushes per 4-wide level; 4-wide depth = ceil(binary depth / 2)
-    if (((r->bvh.max_depth + 1) / 2) * 3 > (uint32_t)(kLdsStack + kSpillStack))
+    if (r->bvh.depth4 * 3 > (uint32_t)(kLdsStack + kSpillStack))
       return fail(PT_ERR_UNSUPPORTED, "BVH too deep for the traversal stack (degenerate geometry: thousands of coincident triangles?)");
     S.nodes = r->bvh.nodes;
     S.tris = r->bvh.tris;

@@ -17,6 +17,8 @@ using namespace pt;
 
 namespace {
 
+static unsigned long long g_nodes = 0, g_tris = 0, g_rays = 0;  // traversal statistics of emu_debug_sample (experiments)
+
 struct Emu {
   HostScene hs;
   std::vector<float> lut;
@@ -54,6 +56,51 @@ uint32_t build_bin(std::vector<BinNode>& bin, std::vector<uint32_t>& order, cons
   uint32_t r = build_bin(bin, order, boxes, mid, first + count - mid);
   bin[idx] = {l, r, bb};
   return idx;
+}
+
+// LBVH-like topology (experiments: EMU_MORTON=1): sort by 63-bit Morton code of the box centre, split ranges at the highest
+// differing bit (what the Karras tree of lbvh.hip encodes).
+static uint64_t expand21(uint64_t v) { v &= 0x1fffff; v = (v | v << 32) & 0x1f00000000ffffull; v = (v | v << 16) & 0x1f0000ff0000ffull;
+  v = (v | v << 8) & 0x100f00f00f00f00full; v = (v | v << 4) & 0x10c30c30c30c30c3ull; v = (v | v << 2) & 0x1249249249249249ull; return v; }
+uint32_t build_morton(std::vector<BinNode>& bin, const std::vector<uint32_t>& order, const std::vector<uint64_t>& keys, const std::vector<Box3>& boxes,
+                      uint32_t first, uint32_t count) {
+  if (count == 1) return kLeafBit | first;
+  uint32_t split = first + count / 2;
+  const uint64_t a = keys[first], b = keys[first + count - 1];
+  if (a != b) {
+    const int bit = 63 - __builtin_clzll(a ^ b);
+    uint32_t lo = first, hi = first + count - 1;  // first index whose `bit` is set
+    while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if ((keys[mid] >> bit) & 1) hi = mid; else lo = mid + 1; }
+    split = lo;
+  }
+  const uint32_t idx = (uint32_t)bin.size();
+  bin.push_back({});
+  const uint32_t l = build_morton(bin, order, keys, boxes, first, split - first);
+  const uint32_t r = build_morton(bin, order, keys, boxes, split, first + count - split);
+  Box3 bb;
+  auto box_of = [&](uint32_t ref) { return (ref & kLeafBit) ? boxes[order[ref & ~kLeafBit]] : bin[ref].box; };
+  const Box3 bl = box_of(l), br = box_of(r);
+  for (int k = 0; k < 3; k++) { bb.lo[k] = std::min(bl.lo[k], br.lo[k]); bb.hi[k] = std::max(bl.hi[k], br.hi[k]); }
+  bin[idx] = {l, r, bb};
+  return idx;
+}
+static float half_area(const Box3& b) { const float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2]; return x * y + y * z + z * x; }
+
+// EMU_SAH_COLLAPSE=1: open the child with the largest surface area until four slots are used
+void collapse_sah(Emu& e, const std::vector<BinNode>& bin, const std::vector<uint32_t>& order, const std::vector<Box3>& boxes, uint32_t i) {
+  uint32_t refs[4] = {bin[i].left, bin[i].right, 0, 0}; int count = 2;
+  auto box_of = [&](uint32_t ref) { return (ref & kLeafBit) ? boxes[order[ref & ~kLeafBit]] : bin[ref].box; };
+  while (count < 4) {
+    int best = -1; float ba = -1.0f;
+    for (int k = 0; k < count; k++) if (!(refs[k] & kLeafBit)) { const float a = half_area(box_of(refs[k])); if (a > ba) { ba = a; best = k; } }
+    if (best < 0) break;
+    const uint32_t r = refs[best];
+    refs[best] = bin[r].left; refs[count++] = bin[r].right;
+  }
+  Box3 bx[4];
+  for (int k = 0; k < count; k++) bx[k] = inflate_box(box_of(refs[k]));
+  e.nodes[i] = quantize_node4(bx, refs, count);
+  for (int k = 0; k < count; k++) if (!(refs[k] & kLeafBit)) collapse_sah(e, bin, order, boxes, refs[k]);
 }
 
 void collapse(Emu& e, const std::vector<BinNode>& bin, const std::vector<uint32_t>& order, const std::vector<Box3>& boxes, uint32_t i) {
@@ -116,8 +163,26 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
   uint32_t root = kInvalidRef;
   if (!tmp.empty()) {
     std::vector<BinNode> bin;
-    root = build_bin(bin, order, boxes, 0, (uint32_t)tmp.size());
-    if (!(root & kLeafBit)) { e->nodes.assign(bin.size(), BvhNode{}); collapse(*e, bin, order, boxes, root); }
+    if (getenv("EMU_MORTON")) {
+      Box3 sb; for (int k = 0; k < 3; k++) { sb.lo[k] = 1e30f; sb.hi[k] = -1e30f; }
+      for (auto& b : boxes) for (int k = 0; k < 3; k++) { sb.lo[k] = std::min(sb.lo[k], b.lo[k]); sb.hi[k] = std::max(sb.hi[k], b.hi[k]); }
+      const float ext = std::max(sb.hi[0] - sb.lo[0], std::max(sb.hi[1] - sb.lo[1], sb.hi[2] - sb.lo[2]));
+      const float scale = ext > 0 ? 2097152.0f / ext : 0.0f;
+      std::vector<uint64_t> code(boxes.size());
+      for (size_t i = 0; i < boxes.size(); i++) {
+        uint64_t c = 0;
+        for (int k = 0; k < 3; k++) { float q = (0.5f * (boxes[i].lo[k] + boxes[i].hi[k]) - sb.lo[k]) * scale; q = std::min(std::max(q, 0.0f), 2097151.0f); c |= expand21((uint64_t)q) << (2 - k); }
+        code[i] = c;
+      }
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
+      std::vector<uint64_t> keys(order.size());
+      for (size_t i = 0; i < order.size(); i++) keys[i] = code[order[i]];
+      root = build_morton(bin, order, keys, boxes, 0, (uint32_t)tmp.size());
+    } else root = build_bin(bin, order, boxes, 0, (uint32_t)tmp.size());
+    if (!(root & kLeafBit)) {
+      e->nodes.assign(bin.size(), BvhNode{});
+      if (getenv("EMU_SAH_COLLAPSE")) collapse_sah(*e, bin, order, boxes, root); else collapse(*e, bin, order, boxes, root);
+    }
   }
   e->tris.resize(tmp.size());
   for (size_t i = 0; i < order.size(); i++) e->tris[i] = tmp[order[i]];
@@ -165,7 +230,8 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
         TraversalStack st; st.lds = lds.data(); st.pend = pend.data(); st.lds_stride = 1; st.spill = spill.data(); st.spill_stride = 1;
         TraversalCount tc;
         const float ir = S.has_alpha ? Halton{S.halton, rg.offset, dim}.sample1d() : 0.0f;
-        RayHit hit = traverse<false, false>(S, o, d, 1e-3f, kInf, ir, st, &tc);
+        RayHit hit = traverse<false, true>(S, o, d, 1e-3f, kInf, ir, st, &tc);
+        g_nodes += tc.nodes; g_tris += tc.tris; g_rays++;
         if (hits && hit.tri != kInvalidRef) { hits[((size_t)b * NP + pid) * 2] = S.tris[hit.tri].inst; hits[((size_t)b * NP + pid) * 2 + 1] = S.tris[hit.tri].prim; }
         if (hit.tri == kInvalidRef) {
           if (S.env_texture >= 0) L = L + stage_miss(S, d, att, b, lastPdf, lastSpec);
@@ -203,6 +269,7 @@ void emu_trace_primary(void* h, uint32_t sample, pt_hit_record* out) {
       else { r.t = r.u = r.v = 0; r.instance = r.primitive = -1; }
     }
 }
+void emu_get_counts(unsigned long long out[3]) { out[0] = g_nodes; out[1] = g_tris; out[2] = g_rays; g_nodes = g_tris = g_rays = 0; }
 float emu_halton(void* h, uint32_t i, uint32_t d) { return halton(((Emu*)h)->halton.data(), i, d); }
 
 }  // extern "C"
