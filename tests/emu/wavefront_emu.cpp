@@ -58,6 +58,8 @@ uint32_t build_bin(std::vector<BinNode>& bin, std::vector<uint32_t>& order, cons
   return idx;
 }
 
+static float half_area(const Box3& b) { const float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2]; return x * y + y * z + z * x; }
+
 // LBVH-like topology (experiments: EMU_MORTON=1): sort by 63-bit Morton code of the box centre, split ranges at the highest
 // differing bit (what the Karras tree of lbvh.hip encodes).
 static uint64_t expand21(uint64_t v) { v &= 0x1fffff; v = (v | v << 32) & 0x1f00000000ffffull; v = (v | v << 16) & 0x1f0000ff0000ffull;
@@ -84,7 +86,6 @@ uint32_t build_morton(std::vector<BinNode>& bin, const std::vector<uint32_t>& or
   bin[idx] = {l, r, bb};
   return idx;
 }
-static float half_area(const Box3& b) { const float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2]; return x * y + y * z + z * x; }
 
 // EMU_SAH_COLLAPSE=1: open the child with the largest surface area until four slots are used
 void collapse_sah(Emu& e, const std::vector<BinNode>& bin, const std::vector<uint32_t>& order, const std::vector<Box3>& boxes, uint32_t i) {
@@ -101,6 +102,68 @@ void collapse_sah(Emu& e, const std::vector<BinNode>& bin, const std::vector<uin
   for (int k = 0; k < count; k++) bx[k] = inflate_box(box_of(refs[k]));
   e.nodes[i] = quantize_node4(bx, refs, count);
   for (int k = 0; k < count; k++) if (!(refs[k] & kLeafBit)) collapse_sah(e, bin, order, boxes, refs[k]);
+}
+
+// EMU_SAH_BUILD=1: top-down binned-SAH builder (16 bins, centroid bounds) — a quality yardstick for the GPU's Morton tree
+uint32_t build_sah(std::vector<BinNode>& bin, std::vector<uint32_t>& order, const std::vector<Box3>& boxes, uint32_t first, uint32_t count) {
+  if (count == 1) return kLeafBit | first;
+  Box3 bb, cb;
+  for (int k = 0; k < 3; k++) { bb.lo[k] = cb.lo[k] = 1e30f; bb.hi[k] = cb.hi[k] = -1e30f; }
+  for (uint32_t i = first; i < first + count; i++) {
+    const Box3& b = boxes[order[i]];
+    for (int k = 0; k < 3; k++) {
+      bb.lo[k] = std::min(bb.lo[k], b.lo[k]); bb.hi[k] = std::max(bb.hi[k], b.hi[k]);
+      const float c = 0.5f * (b.lo[k] + b.hi[k]);
+      cb.lo[k] = std::min(cb.lo[k], c); cb.hi[k] = std::max(cb.hi[k], c);
+    }
+  }
+  constexpr int NB = 16;
+  float best_cost = 1e30f; int best_axis = -1, best_split = 0;
+  for (int axis = 0; axis < 3; axis++) {
+    const float ext = cb.hi[axis] - cb.lo[axis];
+    if (!(ext > 0.0f)) continue;
+    Box3 bbox[NB]; int bcnt[NB] = {0};
+    for (int b = 0; b < NB; b++) for (int k = 0; k < 3; k++) { bbox[b].lo[k] = 1e30f; bbox[b].hi[k] = -1e30f; }
+    for (uint32_t i = first; i < first + count; i++) {
+      const Box3& b = boxes[order[i]];
+      int bi = (int)((0.5f * (b.lo[axis] + b.hi[axis]) - cb.lo[axis]) / ext * NB); bi = std::min(std::max(bi, 0), NB - 1);
+      bcnt[bi]++;
+      for (int k = 0; k < 3; k++) { bbox[bi].lo[k] = std::min(bbox[bi].lo[k], b.lo[k]); bbox[bi].hi[k] = std::max(bbox[bi].hi[k], b.hi[k]); }
+    }
+    float right_area[NB]; int right_cnt[NB];
+    Box3 acc; for (int k = 0; k < 3; k++) { acc.lo[k] = 1e30f; acc.hi[k] = -1e30f; }
+    int c = 0;
+    for (int b = NB - 1; b > 0; b--) {
+      c += bcnt[b];
+      for (int k = 0; k < 3; k++) { acc.lo[k] = std::min(acc.lo[k], bbox[b].lo[k]); acc.hi[k] = std::max(acc.hi[k], bbox[b].hi[k]); }
+      right_area[b] = c ? half_area(acc) : 0.0f; right_cnt[b] = c;
+    }
+    for (int k = 0; k < 3; k++) { acc.lo[k] = 1e30f; acc.hi[k] = -1e30f; }
+    c = 0;
+    for (int b = 0; b < NB - 1; b++) {
+      c += bcnt[b];
+      for (int k = 0; k < 3; k++) { acc.lo[k] = std::min(acc.lo[k], bbox[b].lo[k]); acc.hi[k] = std::max(acc.hi[k], bbox[b].hi[k]); }
+      if (c == 0 || right_cnt[b + 1] == 0) continue;
+      const float cost = half_area(acc) * c + right_area[b + 1] * right_cnt[b + 1];
+      if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = b; }
+    }
+  }
+  uint32_t mid;
+  if (best_axis < 0) mid = first + count / 2;
+  else {
+    const float ext = cb.hi[best_axis] - cb.lo[best_axis];
+    auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t a) {
+      int bi = (int)((0.5f * (boxes[a].lo[best_axis] + boxes[a].hi[best_axis]) - cb.lo[best_axis]) / ext * NB); bi = std::min(std::max(bi, 0), NB - 1);
+      return bi <= best_split; });
+    mid = (uint32_t)(it - order.begin());
+    if (mid == first || mid == first + count) mid = first + count / 2;
+  }
+  const uint32_t idx = (uint32_t)bin.size();
+  bin.push_back({});
+  const uint32_t l = build_sah(bin, order, boxes, first, mid - first);
+  const uint32_t r = build_sah(bin, order, boxes, mid, first + count - mid);
+  bin[idx] = {l, r, bb};
+  return idx;
 }
 
 void collapse(Emu& e, const std::vector<BinNode>& bin, const std::vector<uint32_t>& order, const std::vector<Box3>& boxes, uint32_t i) {
@@ -178,7 +241,8 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
       std::vector<uint64_t> keys(order.size());
       for (size_t i = 0; i < order.size(); i++) keys[i] = code[order[i]];
       root = build_morton(bin, order, keys, boxes, 0, (uint32_t)tmp.size());
-    } else root = build_bin(bin, order, boxes, 0, (uint32_t)tmp.size());
+    } else if (getenv("EMU_SAH_BUILD")) root = build_sah(bin, order, boxes, 0, (uint32_t)tmp.size());
+    else root = build_bin(bin, order, boxes, 0, (uint32_t)tmp.size());
     if (!(root & kLeafBit)) {
       e->nodes.assign(bin.size(), BvhNode{});
       if (getenv("EMU_SAH_COLLAPSE")) collapse_sah(*e, bin, order, boxes, root); else collapse(*e, bin, order, boxes, root);
