@@ -59,7 +59,8 @@ struct RayGenOut { vec3 o, d; uint32_t offset, dim; };
 PT_HD RayGenOut stage_raygen(const DeviceScene& S, uint32_t px, uint32_t py, uint32_t sample) {
   Halton h{S.halton, halton_offset(px, py, sample), 0};
   const vec2 pixelSample = h.sample2d();  // dims 0-1 (kernel.metal:497)
-  const vec2 lensSample = h.sample2d();   // dims 2-3
+  vec2 lensSample = {0.0f, 0.0f};         // dims 2-3: consumed always, evaluated only by a thin-lens camera
+  if (S.camera.apertureRadius > 0.0f) lensSample = h.sample2d(); else h.dim += 2;
   const pt_camera_data& cam = S.camera;
   vec3 origin = ld3(cam.position);
   if (cam.apertureRadius > 0.0f) {  // kernel.metal:205-226
@@ -219,9 +220,20 @@ PT_HD ShadeOut stage_shade(const DeviceScene& S, const ShadeIn& in) {
   // ---- BSDF sample (kernel.metal:550-556) ----
   const vec2 r01 = halton.sample2d();
   const float r2 = halton.sample1d();
-  const float r3 = halton.sample1d();
-  const vec2 rc = halton.sample2d();
   const ShadingContext ctx = make_shading_context(S, material, surfaceUV);
+  // r3 picks the lobe (bsdf.metal:228-252: r.w < pClearcoat / pMetallic / pTransparent).  Without a coat the thresholds
+  // are m and m + (1-m)t; a threshold <= 0 is never passed and one >= 1 always is (r.w < 1), so r3 only matters when one
+  // of them lies strictly inside (0,1) — not for a pure dielectric, a pure metal or pure glass.  The dimension is consumed
+  // either way.
+  float r3 = 0.0f;
+  {
+    const float m = ctx.metallic, pT = m + (1.0f - m) * ctx.transmission;
+    if (ctx.clearcoat > 0.0f || (m > 0.0f && m < 1.0f) || (pT > 0.0f && pT < 1.0f)) r3 = halton.sample1d(); else halton.dim += 1;
+  }
+  // rc only feeds the clearcoat micro-normal (bsdf.metal:231-236): the two dimensions are always consumed, the radical
+  // inverses only computed when a coat exists (Halton is 18 % of this kernel)
+  vec2 rc = {0.0f, 0.0f};
+  if (ctx.clearcoat > 0.0f) rc = halton.sample2d(); else halton.dim += 2;
   const BSDF bsdf(ctx, S.flags, S.luts, wo);
 #ifdef PT_EXP_NO_SAMPLE  // timing experiment only: cosine-weighted diffuse sample instead of the principled lobes
   BsdfSample sample;
@@ -307,7 +319,9 @@ PT_HD ShadeOut stage_shade(const DeviceScene& S, const ShadeIn& in) {
   vec3 att = in.att * (sample.f * fabsf(sample.wi.z) / sample.pdf);  // :650
   if (in.bounce > 0) {                                               // :655-661
     const float q = fmaxf(0.0f, 1.0f - fmaxf(att.x, fmaxf(att.y, att.z)));
-    if (halton.sample1d() < q) { out.dim = halton.dim; return out; }
+    if (q > 0.0f) {  // (q == 0: no sample is below it; the dimension is consumed without evaluating it)
+      if (halton.sample1d() < q) { out.dim = halton.dim; return out; }
+    } else halton.dim += 1;
     att = att / (1.0f - q);
   }
   out.dim = halton.dim;
