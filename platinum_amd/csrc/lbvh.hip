@@ -292,9 +292,126 @@ __global__ void __launch_bounds__(256) k_reorder_tris(int n, const uint32_t* __r
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) tris_out[i] = tris_in[order[i]];
 }
-__global__ void k_seed_queue(uint32_t* q, uint32_t* counters) { q[0] = 0u; counters[0] = 0u; counters[1] = 0u; }
+__global__ void k_seed_queue(uint32_t* q, uint32_t* counters, uint32_t root) { q[0] = root; counters[0] = 0u; counters[1] = 0u; }
+
+// ---- PLOC: parallel locally-ordered clustering (Meister & Bittner 2018) over the Morton order -----------------------------
+// Every cluster looks +-kPlocRadius positions around itself for the neighbour whose union with it has the smallest surface
+// area; mutual nearest neighbours merge into a new binary node, the cluster array is compacted (order preserved) and the
+// search repeats until one cluster is left.  Node indices and positions come from prefix sums, so the tree is the same on
+// every run.  Against the Karras radix tree over the same order: 11-17 % fewer node visits and 7-21 % fewer triangle tests
+// per ray (host build of the same traversal, tests/emu EMU_PLOC).
+constexpr int kPlocRadius = 8;
+__device__ __forceinline__ float merged_half_area(const Box& a, const Box& b) {
+  const float x = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]);
+  const float y = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]);
+  const float z = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
+  return x * y + y * z + z * x;
+}
+__global__ void __launch_bounds__(256) k_ploc_init(uint32_t n, const Box* __restrict__ leaf_boxes, const uint32_t* __restrict__ order,
+                                                    uint32_t* __restrict__ cl_ref, Box* __restrict__ cl_box) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  cl_ref[i] = kLeafBit | i;
+  cl_box[i] = leaf_boxes[order[i]];
+}
+__global__ void __launch_bounds__(256) k_ploc_nn(uint32_t n, const Box* __restrict__ cl_box, uint32_t* __restrict__ nn) {
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= (int)n) return;
+  const Box me = cl_box[i];
+  float best = kInf;
+  int bj = i;
+  // candidate order: the pairing partner i ^ 1 first, then by distance (left before right); a strict `<` keeps the first
+  // of equal candidates, so a run of identical boxes pairs up as (0,1)(2,3)... instead of one merge per pass
+  auto consider = [&](int j) {
+    if (j < 0 || j >= (int)n || j == i) return;
+    const float a = merged_half_area(me, cl_box[j]);
+    if (a < best) { best = a; bj = j; }
+  };
+  consider(i ^ 1);
+  for (int d = 1; d <= kPlocRadius; d++) { consider(i - d); consider(i + d); }
+  nn[i] = (uint32_t)bj;
+}
+__global__ void __launch_bounds__(256) k_ploc_flags(uint32_t n, const uint32_t* __restrict__ nn, uint32_t* __restrict__ merge_flag,
+                                                     uint32_t* __restrict__ keep_flag) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t j = nn[i];
+  const bool mutual = j != i && nn[j] == i;
+  merge_flag[i] = (mutual && i < j) ? 1u : 0u;
+  keep_flag[i] = (mutual && i > j) ? 0u : 1u;
+}
+__global__ void __launch_bounds__(256) k_ploc_apply(uint32_t n, const uint32_t* __restrict__ nn, const uint32_t* __restrict__ merge_flag,
+                                                     const uint32_t* __restrict__ keep_flag, const uint32_t* __restrict__ node_off,
+                                                     const uint32_t* __restrict__ pos, uint32_t base, const uint32_t* __restrict__ cl_ref,
+                                                     const Box* __restrict__ cl_box, uint32_t* __restrict__ out_ref, Box* __restrict__ out_box,
+                                                     uint2* __restrict__ children, Box* __restrict__ node_boxes, uint32_t* __restrict__ counts) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (i == n - 1) { counts[0] = node_off[i] + merge_flag[i]; counts[1] = pos[i] + keep_flag[i]; }
+  if (!keep_flag[i]) return;
+  const uint32_t p = pos[i];
+  if (merge_flag[i]) {
+    const uint32_t j = nn[i], idx = base + node_off[i];
+    const Box a = cl_box[i], b = cl_box[j];
+    Box m;
+    for (int k = 0; k < 3; k++) { m.lo[k] = fminf(a.lo[k], b.lo[k]); m.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
+    children[idx] = make_uint2(cl_ref[i], cl_ref[j]);
+    node_boxes[idx] = m;
+    out_ref[p] = idx;
+    out_box[p] = m;
+  } else {
+    out_ref[p] = cl_ref[i];
+    out_box[p] = cl_box[i];
+  }
+}
 
 #define LB_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = e_; goto done; } } while (0)
+
+// Builds the binary tree by PLOC over the Morton order `order` (n >= 2).  Fills children[] / node_boxes[] (n - 1 slots, the
+// root is the last node created) and *root.  *ok = false when the pass limit is hit (the caller falls back to the radix tree).
+static hipError_t ploc_build(hipStream_t s, uint32_t n, const Box* leaf_boxes, const uint32_t* order, uint2* children, Box* node_boxes,
+                             uint32_t* root, bool* ok) {
+  hipError_t err = hipSuccess;
+  *ok = false;
+  uint32_t* cl_ref[2] = {nullptr, nullptr}; Box* cl_box[2] = {nullptr, nullptr};
+  uint32_t *nn = nullptr, *merge_flag = nullptr, *keep_flag = nullptr, *node_off = nullptr, *pos = nullptr, *counts = nullptr;
+  void* scan_tmp = nullptr; size_t scan_bytes = 0;
+  uint32_t cur = n, base = 0, passes = 0;
+  int a = 0;
+  for (int k = 0; k < 2; k++) { LB_CHECK(hipMalloc(&cl_ref[k], sizeof(uint32_t) * (size_t)n)); LB_CHECK(hipMalloc(&cl_box[k], sizeof(Box) * (size_t)n)); }
+  LB_CHECK(hipMalloc(&nn, sizeof(uint32_t) * (size_t)n)); LB_CHECK(hipMalloc(&merge_flag, sizeof(uint32_t) * (size_t)n));
+  LB_CHECK(hipMalloc(&keep_flag, sizeof(uint32_t) * (size_t)n)); LB_CHECK(hipMalloc(&node_off, sizeof(uint32_t) * (size_t)n));
+  LB_CHECK(hipMalloc(&pos, sizeof(uint32_t) * (size_t)n)); LB_CHECK(hipMalloc(&counts, 2 * sizeof(uint32_t)));
+  LB_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, merge_flag, node_off, (int)n, s));
+  LB_CHECK(hipMalloc(&scan_tmp, scan_bytes));
+  hipLaunchKernelGGL(k_ploc_init, dim3((n + 255) / 256), dim3(256), 0, s, n, leaf_boxes, order, cl_ref[0], cl_box[0]);
+  while (cur > 1) {
+    if (++passes > 256) goto done;  // >= 1 merge per pass is guaranteed, ~30 % per pass is typical: this is a degenerate input
+    const uint32_t blocks = (cur + 255) / 256;
+    hipLaunchKernelGGL(k_ploc_nn, dim3(blocks), dim3(256), 0, s, cur, cl_box[a], nn);
+    hipLaunchKernelGGL(k_ploc_flags, dim3(blocks), dim3(256), 0, s, cur, nn, merge_flag, keep_flag);
+    LB_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, merge_flag, node_off, (int)cur, s));
+    LB_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, keep_flag, pos, (int)cur, s));
+    hipLaunchKernelGGL(k_ploc_apply, dim3(blocks), dim3(256), 0, s, cur, nn, merge_flag, keep_flag, node_off, pos, base, cl_ref[a], cl_box[a],
+                       cl_ref[a ^ 1], cl_box[a ^ 1], children, node_boxes, counts);
+    uint32_t h[2];
+    LB_CHECK(hipMemcpyAsync(h, counts, sizeof(h), hipMemcpyDeviceToHost, s));
+    LB_CHECK(hipStreamSynchronize(s));
+    if (h[0] == 0 || h[1] != cur - h[0] || base + h[0] > n - 1) goto done;  // no progress / inconsistent: fall back
+    base += h[0];
+    cur = h[1];
+    a ^= 1;
+  }
+  if (base == n - 1) {
+    *root = n - 2;  // the last node created
+    *ok = true;
+  }
+done:
+  for (int k = 0; k < 2; k++) { (void)hipFree(cl_ref[k]); (void)hipFree(cl_box[k]); }
+  (void)hipFree(nn); (void)hipFree(merge_flag); (void)hipFree(keep_flag); (void)hipFree(node_off); (void)hipFree(pos); (void)hipFree(counts);
+  (void)hipFree(scan_tmp);
+  return err;
+}
 
 }  // namespace
 
@@ -310,6 +427,8 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
   uint2* children = nullptr; uint32_t *parent_int = nullptr, *parent_leaf = nullptr, *flags = nullptr;
   int* bounds = nullptr; uint32_t* max_depth = nullptr; void* sort_tmp = nullptr; size_t sort_bytes = 0;
   uint32_t depth_h[2] = {0, 0};
+  uint32_t root = 0;
+  bool use_ploc = getenv("PTAMD_RADIX_TREE") == nullptr;  // PLOC by default; the Karras radix tree is the fallback
 
   LB_CHECK(hipMalloc(&tris_tmp, sizeof(TriRec) * (size_t)n));
   LB_CHECK(hipMalloc(&out->tris, sizeof(TriRec) * (size_t)n));
@@ -349,18 +468,28 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
   LB_CHECK(hipMalloc(&sort_tmp, sort_bytes));
   LB_CHECK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 63, s));
 
-  hipLaunchKernelGGL(k_karras, dim3(blocks), dim3(256), 0, s, keys_b, (int)n, children, parent_int, parent_leaf);
-  hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, s, (int)n, children, parent_int, parent_leaf, leaf_boxes, vals_b,
-                     node_boxes, flags, max_depth);
-  LB_CHECK(hipMemcpyAsync(depth_h, max_depth, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  LB_CHECK(hipStreamSynchronize(s));
-  out->max_depth = depth_h[0];
-  {
+  for (;;) {
+    if (use_ploc) {
+      bool ok = false;
+      LB_CHECK(ploc_build(s, n, leaf_boxes, vals_b, children, node_boxes, &root, &ok));
+      if (!ok) { use_ploc = false; continue; }
+      out->max_depth = 0;  // (the binary depth is not tracked on this path; depth4 is what bounds the traversal stack)
+    } else {
+      LB_CHECK(hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)(n - 1), s));
+      LB_CHECK(hipMemsetAsync(max_depth, 0, 4 * sizeof(uint32_t), s));
+      hipLaunchKernelGGL(k_karras, dim3(blocks), dim3(256), 0, s, keys_b, (int)n, children, parent_int, parent_leaf);
+      hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, s, (int)n, children, parent_int, parent_leaf, leaf_boxes, vals_b,
+                         node_boxes, flags, max_depth);
+      LB_CHECK(hipMemcpyAsync(depth_h, max_depth, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      LB_CHECK(hipStreamSynchronize(s));
+      out->max_depth = depth_h[0];
+      root = 0;
+    }
     // level-synchronous SAH collapse; queues live in the sort's scratch (vals_a: 4n bytes, keys_a: 8n bytes)
     uint32_t* q_in = vals_a;
     uint32_t* q_out = reinterpret_cast<uint32_t*>(keys_a);
     uint32_t* counters = max_depth + 2;  // [0] next level's size, [1] nodes emitted
-    hipLaunchKernelGGL(k_seed_queue, dim3(1), dim3(1), 0, s, q_in, counters);
+    hipLaunchKernelGGL(k_seed_queue, dim3(1), dim3(1), 0, s, q_in, counters, root);
     uint32_t n_in = 1, levels = 0, emitted = 0;
     bool too_deep = false;
     while (n_in > 0) {
@@ -375,8 +504,9 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
       std::swap(q_in, q_out);
       levels++;
     }
+    if (too_deep && use_ploc) { use_ploc = false; continue; }  // a pathological cluster tree: try the radix tree
     if (too_deep) {
-      // pathological tree: the even-depth collapse bounds the 4-wide depth by half the binary depth
+      // pathological radix tree: the even-depth collapse bounds the 4-wide depth by half the binary depth
       LB_CHECK(hipMemsetAsync(max_depth + 1, 0, sizeof(uint32_t), s));
       hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, s, (int)n, children, parent_int, leaf_boxes, vals_b, node_boxes, tris_tmp,
                          out->nodes, out->tris, max_depth + 1);
@@ -389,9 +519,10 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
     }
     LB_CHECK(hipGetLastError());
     LB_CHECK(hipStreamSynchronize(s));
-    out->root_ref = 0;
+    out->root_ref = root;
     out->node_count = emitted;
     out->depth4 = levels;
+    break;
   }
 
 done:

@@ -105,7 +105,7 @@ struct DeviceScene {
   const TriRec* tris;
   const ShadeRec* shade_recs;  // tri_count records, same order as tris[]
   uint32_t tri_count;
-  uint32_t root_ref;       // kLeafBit|0 for a single-triangle scene, 0 otherwise, kInvalidRef when empty
+  uint32_t root_ref;       // kLeafBit|0 for a single-triangle scene, the root's node index otherwise, kInvalidRef when empty
   const HaltonEntry* halton;
   LutSet luts;
   const vec4* tex_pixels;

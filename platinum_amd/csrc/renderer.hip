@@ -743,7 +743,7 @@ int pt_get_stats(pt_renderer* r, pt_stats* out) {
   memset(out, 0, sizeof(*out));
   out->triangles = r->tri_count;
   out->bvh_nodes = r->bvh.node_count;
-  out->bvh_max_depth = r->bvh.max_depth;
+  out->bvh_max_depth = r->bvh.depth4;
   out->samples_in_flight = r->samples_in_flight;
   out->upload_ms = r->upload_ms;
   out->bvh_build_ms = r->bvh_ms;

@@ -166,6 +166,46 @@ uint32_t build_sah(std::vector<BinNode>& bin, std::vector<uint32_t>& order, cons
   return idx;
 }
 
+// EMU_PLOC=<radius>: parallel locally-ordered clustering (Meister & Bittner 2018) on the Morton order — prototype of a GPU
+// builder that approaches SAH quality: every cluster finds its nearest neighbour (smallest merged surface area) within
+// +-radius positions, mutual nearest neighbours merge, the array is compacted, repeat.
+uint32_t build_ploc(std::vector<BinNode>& bin, const std::vector<uint32_t>& order, const std::vector<Box3>& boxes, int radius) {
+  struct Cl { uint32_t ref; Box3 box; };
+  std::vector<Cl> c(order.size()), next;
+  for (size_t i = 0; i < order.size(); i++) c[i] = {kLeafBit | (uint32_t)i, boxes[order[i]]};
+  auto merged_area = [](const Box3& a, const Box3& b) {
+    Box3 m; for (int k = 0; k < 3; k++) { m.lo[k] = std::min(a.lo[k], b.lo[k]); m.hi[k] = std::max(a.hi[k], b.hi[k]); }
+    return half_area(m);
+  };
+  std::vector<int> nn;
+  while (c.size() > 1) {
+    const int n = (int)c.size();
+    nn.assign(n, -1);
+    for (int i = 0; i < n; i++) {
+      float best = 1e30f;
+      for (int j = std::max(0, i - radius); j <= std::min(n - 1, i + radius); j++) {
+        if (j == i) continue;
+        const float a = merged_area(c[i].box, c[j].box);
+        if (a < best) { best = a; nn[i] = j; }
+      }
+    }
+    next.clear();
+    for (int i = 0; i < n; i++) {
+      const int j = nn[i];
+      if (nn[j] == i) {
+        if (i < j) {
+          BinNode b; b.left = c[i].ref; b.right = c[j].ref;
+          for (int k = 0; k < 3; k++) { b.box.lo[k] = std::min(c[i].box.lo[k], c[j].box.lo[k]); b.box.hi[k] = std::max(c[i].box.hi[k], c[j].box.hi[k]); }
+          bin.push_back(b);
+          next.push_back({(uint32_t)bin.size() - 1, b.box});
+        }
+      } else next.push_back(c[i]);
+    }
+    c.swap(next);
+  }
+  return c[0].ref;
+}
+
 void collapse(Emu& e, const std::vector<BinNode>& bin, const std::vector<uint32_t>& order, const std::vector<Box3>& boxes, uint32_t i) {
   uint32_t refs[4]; Box3 bx[4]; int count = 0;
   auto add = [&](uint32_t ref) {
@@ -240,7 +280,8 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
       std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
       std::vector<uint64_t> keys(order.size());
       for (size_t i = 0; i < order.size(); i++) keys[i] = code[order[i]];
-      root = build_morton(bin, order, keys, boxes, 0, (uint32_t)tmp.size());
+      if (getenv("EMU_PLOC")) root = build_ploc(bin, order, boxes, atoi(getenv("EMU_PLOC")));
+      else root = build_morton(bin, order, keys, boxes, 0, (uint32_t)tmp.size());
     } else if (getenv("EMU_SAH_BUILD")) root = build_sah(bin, order, boxes, 0, (uint32_t)tmp.size());
     else root = build_bin(bin, order, boxes, 0, (uint32_t)tmp.size());
     if (!(root & kLeafBit)) {
