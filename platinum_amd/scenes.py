@@ -561,6 +561,56 @@ def textured_scene(env=True, area_light=True, alpha=True):
     return sc
 
 
+def random_scene(seed, textures=True):
+    """A seeded random scene for parity fuzzing: 2-10 instances of the reference primitives under arbitrary TRS (non-uniform and
+    mirrored scales included), materials drawn over the whole parameter space of core/material.hpp (exact 0 / 1 corner values
+    over-represented: smooth surfaces, pure metal, pure glass), random light panels, optional textures and environment."""
+    rng = np.random.default_rng(seed)
+    sc = Scene(name=f"random{seed}")
+    meshes = [sc.add_mesh(plane(2.0)), sc.add_mesh(cube(1.0)), sc.add_mesh(sphere(0.6, 8, 12))]
+    tex = []
+    if textures and rng.random() < 0.7:
+        tex.append(sc.add_texture(rng.integers(0, 256, (8, 8, 4), dtype=np.uint8), abi.TEX_RGBA8_SRGB))
+        tex.append(sc.add_texture(rng.integers(8, 256, (4, 8, 2), dtype=np.uint8), abi.TEX_RG8))
+        nm = rng.integers(96, 160, (8, 8, 4), dtype=np.uint8); nm[..., 2] = 230
+        tex.append(sc.add_texture(nm, abi.TEX_RGBA8))
+
+    def corner(lo=0.0, hi=1.0):
+        u = rng.random()
+        return lo if u < 0.25 else (hi if u < 0.45 else float(rng.uniform(lo, hi)))
+
+    def material():
+        m = Material(base_color=(float(rng.uniform(0.05, 1)), float(rng.uniform(0.05, 1)), float(rng.uniform(0.05, 1)),
+                                 1.0 if rng.random() < 0.8 else float(rng.uniform(0.2, 0.9))),
+                     roughness=corner(), metallic=corner(), transmission=corner(), ior=float(rng.uniform(1.05, 2.2)),
+                     anisotropy=0.0 if rng.random() < 0.6 else float(rng.uniform(-0.9, 0.9)), clearcoat=0.0 if rng.random() < 0.6 else float(rng.uniform(0.1, 1)),
+                     clearcoat_roughness=corner(0.0, 0.6), thin_transmission=bool(rng.random() < 0.2))
+        if rng.random() < 0.2:
+            m.emission = (float(rng.uniform(0, 1)), float(rng.uniform(0, 1)), float(rng.uniform(0, 1))); m.emission_strength = float(rng.uniform(0.5, 8))
+        if tex and rng.random() < 0.5:
+            m.base_texture = tex[0]; m.base_texture_has_alpha = bool(rng.random() < 0.3)
+            if rng.random() < 0.5: m.rm_texture = tex[1]
+            if rng.random() < 0.5: m.normal_texture = tex[2]
+        return m
+
+    sc.add_instance(meshes[0], Transform(scale=(6, 1, 6)), [material()])   # a floor so that most paths bounce
+    for _ in range(int(rng.integers(2, 10))):
+        s = rng.uniform(0.3, 1.8, 3) * np.where(rng.random(3) < 0.15, -1.0, 1.0)
+        sc.add_instance(meshes[int(rng.integers(0, 3))],
+                        Transform(translation=tuple(rng.uniform((-3, 0.2, -3), (3, 3, 3))), rotation=tuple(rng.uniform(-3.2, 3.2, 3)), scale=tuple(s)),
+                        [material()])
+    if rng.random() < 0.8:  # a light panel (otherwise: emissive objects or the environment, or darkness)
+        sc.add_instance(meshes[0], Transform(translation=(float(rng.uniform(-1, 1)), 4.5, float(rng.uniform(-1, 1))), rotation=(np.pi, 0, 0)),
+                        [Material(base_color=(0, 0, 0, 1), emission=(1, 1, 1), emission_strength=float(rng.uniform(2, 12)))])
+    if rng.random() < 0.5:
+        sc.env_texture = sc.add_texture(sky_environment(16, 8, sun=(int(rng.integers(0, 14)), int(rng.integers(0, 4)))), abi.TEX_RGBA32F)
+    cam = Camera.with_focal_length(float(rng.uniform(18, 50)))
+    if rng.random() < 0.3:
+        cam.aperture = 2.0; cam.focus_distance = 6.0; cam.roundness = float(rng.uniform(0, 1)); cam.bokeh_power = float(rng.uniform(-1, 1))
+    sc.set_camera(cam, Transform(translation=tuple(rng.uniform((-4, 1, 4), (4, 4, 7))), target=(0, 1, 0), track=True))
+    return sc
+
+
 def atrium_scene(env_size=(4096, 2048), columns=20):
     """C5 stand-in (BASELINE.json configs[4]: "glTF Sponza-class scene with mixed Lambert/GGX/emissive + EXR envmap"): no
     Sponza asset exists offline, so this is a procedural colonnade of the same class — ~260 k triangles, textured

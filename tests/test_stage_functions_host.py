@@ -51,3 +51,19 @@ def test_thin_lens_camera_and_clearcoat_material():
     ro, ho = o.debug_sample(0)
     re_, he = e.debug_sample(0)
     assert np.array_equal(ho, he) and ro.tobytes() == re_.tobytes()
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_scene_fuzz_stage_functions(seed):
+    """scenes.random_scene: arbitrary TRS (mirrored / non-uniform scale), the whole material parameter space with the exact
+    0 / 1 corners over-represented, thin-lens cameras, textures, environment, both integrators."""
+    sc = scenes.random_scene(seed)
+    p = make_params(48, 27, 1, 6, integrator=abi.INTEGRATOR_MIS if seed % 4 else abi.INTEGRATOR_SIMPLE)
+    o, e = oracle_lib.OracleScene(sc, p), emu_lib.EmuScene(sc, p)
+    assert bytes(o.constants()) == bytes(e.constants())
+    assert [bytes(a) for a in o.lights()] == [bytes(b) for b in e.lights()]
+    ro, ho = o.debug_sample(0)
+    re_, he = e.debug_sample(0)
+    nan = np.isnan(ro)
+    assert np.array_equal(ho, he) and np.array_equal(nan, np.isnan(re_))
+    assert np.array_equal(ro.view(np.uint32)[~nan], re_.view(np.uint32)[~nan])
