@@ -67,3 +67,22 @@ def test_random_scene_fuzz_stage_functions(seed):
     nan = np.isnan(ro)
     assert np.array_equal(ho, he) and np.array_equal(nan, np.isnan(re_))
     assert np.array_equal(ro.view(np.uint32)[~nan], re_.view(np.uint32)[~nan])
+
+
+def test_halton_fp32_division_boundaries_equal_oracle():
+    """The strength-reduced radical inverse of pt_sampler.h at the multiples of every dimension's chunk (+-1), around 2^21 and at
+    the top of the 32-bit range.  (An fp32 division of the small quotients was tried on top of it: bit-exact, but slower.)"""
+    e = emu_lib.EmuScene(scenes.cornell_scene(), make_params(8, 8, 1, 2))
+    L = oracle_lib.lib()
+    for d in list(range(0, 64)) + list(range(64, 620, 7)) + [619]:
+        p = L.orc_prime(d)
+        chunk = p
+        while chunk * p < 65536:
+            chunk *= p
+        ks = [1, 2, (1 << 21) // chunk - 1, (1 << 21) // chunk, (1 << 21) // chunk + 1, (1 << 32) // chunk - 1]
+        for k in ks:
+            for i in (k * chunk - 1, k * chunk, k * chunk + 1):
+                if 0 <= i < (1 << 32):
+                    assert e.halton(i, d) == L.orc_halton(i, d), (i, d)
+        for i in ((1 << 21) - 1, 1 << 21, (1 << 21) + 1, (1 << 32) - 1):
+            assert e.halton(i, d) == L.orc_halton(i, d), (i, d)
