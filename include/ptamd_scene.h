@@ -39,6 +39,9 @@ int pt_scene_import_gltf(pt_scene* s, const char* gltf_or_glb_path, int options)
 /* Adds an RGBA32F lat-long image as a texture asset and makes it the scene environment (what the frontend's
  * "load environment" does: TextureLoader HDR path + Environment::setTexture). */
 int pt_scene_set_environment(pt_scene* s, const float* rgba, uint32_t width, uint32_t height, const char* name);
+/* The same from a file, as TextureLoader::loadFromFile(path, name, TextureType::HDR) (loaders/texture.cpp:86-103): ".exr" is read like
+ * tinyexr's LoadEXR (scanline NONE / RLE / ZIPS / ZIP, HALF / FLOAT), anything else like stbi_loadf (Radiance .hdr). */
+int pt_scene_load_environment(pt_scene* s, const char* path);
 
 typedef struct pt_scene_counts {
   uint32_t nodes, meshes, textures, materials, cameras, instances; /* instances: visible nodes with a mesh */

@@ -8,7 +8,7 @@
 #include "tinyexr.h"
 
 int main(int argc, char** argv) {
-  if (argc != 3) { fprintf(stderr, "usage: exr2raw in.exr out.f32\n"); return 2; }
+  if (argc != 3 && argc != 4) { fprintf(stderr, "usage: exr2raw in.exr out.f32 [rgba]\n"); return 2; }
   float* rgba = nullptr; int w = 0, h = 0; const char* err = nullptr;
   int r = LoadEXR(&rgba, &w, &h, argv[1], &err);
   if (r < 0) { fprintf(stderr, "LoadEXR failed: %s\n", err ? err : "?"); return 1; }
@@ -16,7 +16,8 @@ int main(int argc, char** argv) {
   if (!f) return 1;
   int hdr[2] = {w, h};
   fwrite(hdr, sizeof(int), 2, f);
-  for (int i = 0; i < w * h; i++) fwrite(&rgba[4 * i + 3], sizeof(float), 1, f);  // renderer_pt.cpp:405-407
+  if (argc == 4) fwrite(rgba, sizeof(float), (size_t)w * h * 4, f);  // all four channels: the environment-map path (loaders/texture.cpp:93)
+  else for (int i = 0; i < w * h; i++) fwrite(&rgba[4 * i + 3], sizeof(float), 1, f);  // renderer_pt.cpp:405-407
   fclose(f);
   free(rgba);
   return 0;

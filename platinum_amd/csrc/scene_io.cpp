@@ -735,6 +735,19 @@ int pt_scene_set_environment(pt_scene* s, const float* rgba, uint32_t w, uint32_
     s->s->env_texture = id; s->s->has_env = true; s->s->env_alias.clear();  // rebuilt by pt_start_render (core/environment.cpp:5-91)
   });
 }
+int pt_scene_load_environment(pt_scene* s, const char* path) {
+  if (!s || !path) { ptio::g_error = "null argument"; return PT_ERR_INVALID_ARGUMENT; }
+  uint32_t w = 0, h = 0;
+  std::vector<float> px;
+  const int rc = guarded([&] {
+    const std::string p(path);
+    const bool exr = p.size() >= 4 && p.compare(p.size() - 4, 4, ".exr") == 0;
+    px = exr ? ptio::read_exr_rgba(p, &w, &h) : ptio::read_radiance_hdr_rgba(p, &w, &h);
+  });
+  if (rc != PT_OK) return rc;
+  const char* slash = strrchr(path, '/');
+  return pt_scene_set_environment(s, px.data(), w, h, slash ? slash + 1 : path);
+}
 int pt_scene_get_counts(const pt_scene* s, pt_scene_counts* out) {
   if (!s || !out) { ptio::g_error = "null argument"; return PT_ERR_INVALID_ARGUMENT; }
   return guarded([&] { s->s->counts(out); });

@@ -117,6 +117,8 @@ void save_json(const Scene& s, const std::string& path);
 void import_gltf(Scene& s, const std::string& path, int options);   // scene_gltf.cpp
 void generate_tangents(const pt_float3* positions, pt_vertex_data* vdata, uint32_t vertex_count, const uint32_t* indices,
                        uint32_t triangle_count);                     // scene_gltf.cpp
+std::vector<float> read_exr_rgba(const std::string& path, uint32_t* w, uint32_t* h);            // scene_image.cpp
+std::vector<float> read_radiance_hdr_rgba(const std::string& path, uint32_t* w, uint32_t* h);   // scene_image.cpp
 std::vector<uint8_t> decode_png_rgba8(const uint8_t* data, size_t len, uint32_t* w, uint32_t* h);  // scene_gltf.cpp
 
 }  // namespace ptio

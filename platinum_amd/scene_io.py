@@ -24,6 +24,7 @@ SCENE_SYMBOLS = [
     ("pt_scene_save_json", C.c_int, [C.c_void_p, C.c_char_p]),
     ("pt_scene_import_gltf", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("pt_scene_set_environment", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p]),
+    ("pt_scene_load_environment", C.c_int, [C.c_void_p, C.c_char_p]),
     ("pt_scene_get_counts", C.c_int, [C.c_void_p, C.POINTER(SceneCounts)]),
     ("pt_scene_get_camera", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint32]),
     ("pt_scene_add_camera", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_uint64)]),
@@ -89,6 +90,10 @@ class SceneFile:
         px = np.ascontiguousarray(rgba, dtype=np.float32)
         assert px.ndim == 3 and px.shape[2] == 4
         _check(_lib().pt_scene_set_environment(self._h, px.ctypes.data, px.shape[1], px.shape[0], name.encode()))
+
+    def load_environment(self, path):
+        """An .exr (as tinyexr LoadEXR) or Radiance .hdr (as stbi_loadf) file becomes the scene environment."""
+        _check(_lib().pt_scene_load_environment(self._h, str(path).encode()))
 
     def counts(self):
         c = SceneCounts()

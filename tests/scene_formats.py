@@ -267,3 +267,116 @@ def mikkt_reference_tangents(positions, vertex_data, indices):
     lib.genTangSpaceDefault.argtypes = [C.POINTER(Context)]
     lib.genTangSpaceDefault(C.byref(ctx))
     return out
+
+
+# ---- OpenEXR / Radiance HDR writers (environment-map fixtures) --------------------------------------------------------
+def write_exr(path, channels, compression="zip", pixel_type="float", data_window_origin=(0, 0), line_order=0):
+    """channels: dict name -> (H, W) float array.  Single-part scanline OpenEXR 2.0: NONE / RLE / ZIPS / ZIP, HALF or FLOAT."""
+    names = sorted(channels)  # the file stores channels in alphabetical order
+    h, w = channels[names[0]].shape
+    comp = {"none": 0, "rle": 1, "zips": 2, "zip": 3}[compression]
+    ptype = {"half": 1, "float": 2}[pixel_type]
+    dt = np.float16 if ptype == 1 else np.float32
+
+    def attr(name, typ, data):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(data)) + data
+
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<IB3xII", ptype, 0, 1, 1) for n in names) + b"\0"
+    x0, y0 = data_window_origin
+    win = struct.pack("<iiii", x0, y0, x0 + w - 1, y0 + h - 1)
+    hdr = struct.pack("<II", 20000630, 2)
+    hdr += attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([comp]))
+    hdr += attr("dataWindow", "box2i", win) + attr("displayWindow", "box2i", win) + attr("lineOrder", "lineOrder", bytes([line_order]))
+    hdr += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0))
+    hdr += attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    lines_per_block = 16 if comp == 3 else 1
+    starts = list(range(0, h, lines_per_block))
+    if line_order == 1:
+        starts = starts[::-1]  # decreasing y: blocks are stored bottom-up, the offset table is still indexed by increasing y
+
+    def pack_block(y):
+        raw = b"".join(np.ascontiguousarray(channels[n][yy], dtype=dt).tobytes() for yy in range(y, min(h, y + lines_per_block)) for n in names)
+        if comp == 0:
+            return raw
+        a = np.frombuffer(raw, dtype=np.uint8)
+        inter = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)      # de-interleave into two halves
+        pred = np.empty_like(inter)
+        pred[0] = inter[0]
+        pred[1:] = (inter[1:] - inter[:-1] + 128 + 256) % 256            # delta predictor
+        pb = pred.astype(np.uint8).tobytes()
+        if comp == 1:
+            out = bytearray()
+            i = 0
+            while i < len(pb):  # simple RLE: runs of >= 3 equal bytes, else literals
+                j = i
+                while j + 1 < len(pb) and pb[j + 1] == pb[i] and j - i < 126:
+                    j += 1
+                if j - i >= 2:
+                    out += bytes([j - i]) + pb[i:i + 1]
+                    i = j + 1
+                else:
+                    k = i
+                    while k < len(pb) and k - i < 127 and not (k + 2 < len(pb) and pb[k] == pb[k + 1] == pb[k + 2]):
+                        k += 1
+                    out += bytes([(-(k - i)) & 0xFF]) + pb[i:k]
+                    i = k
+            cb = bytes(out)
+        else:
+            cb = zlib.compress(pb, 6)
+        return cb if len(cb) < len(raw) else raw  # OpenEXR stores a block raw when compression does not pay
+
+    blocks = {y: pack_block(y) for y in starts}
+    table_pos = len(hdr)
+    pos = table_pos + 8 * len(starts)
+    offsets = {}
+    body = b""
+    for y in starts:
+        offsets[y] = pos
+        chunk = struct.pack("<iI", y + y0, len(blocks[y])) + blocks[y]
+        body += chunk
+        pos += len(chunk)
+    table = b"".join(struct.pack("<Q", offsets[y]) for y in sorted(starts))
+    with open(path, "wb") as f:
+        f.write(hdr + table + body)
+
+
+def write_radiance_hdr(path, rgbe, rle=True):
+    """rgbe: (H, W, 4) uint8.  New-style RLE scanlines (per channel) or flat."""
+    h, w, _ = rgbe.shape
+    out = bytearray(b"#?RADIANCE\n# test\nFORMAT=32-bit_rle_rgbe\n\n" + f"-Y {h} +X {w}\n".encode())
+    for y in range(h):
+        if not rle or w < 8 or w >= 32768:
+            out += rgbe[y].tobytes()
+            continue
+        out += bytes([2, 2, w >> 8, w & 255])
+        for c in range(4):
+            row = rgbe[y, :, c].tobytes()
+            i = 0
+            while i < w:
+                j = i
+                while j + 1 < w and row[j + 1] == row[i] and j - i < 126:
+                    j += 1
+                if j - i >= 2:
+                    out += bytes([128 + (j - i + 1), row[i]])
+                    i = j + 1
+                else:
+                    k = i
+                    while k < w and k - i < 128 and not (k + 2 < w and row[k] == row[k + 1] == row[k + 2]):
+                        k += 1
+                    out += bytes([k - i]) + row[i:k]
+                    i = k
+    with open(path, "wb") as f:
+        f.write(bytes(out))
+
+
+EXR2RAW_PATH = os.path.join(ROOT, "oracle", "_ref", "exr2raw")
+
+
+def tinyexr_reference_rgba(exr_path, tmp_dir):
+    """The reference's own tinyexr LoadEXR (oracle/_ref/exr2raw, compiled from /root/reference/deps/tinyexr where it lies)."""
+    import subprocess
+    out = os.path.join(tmp_dir, "ref.f32")
+    subprocess.check_call([EXR2RAW_PATH, exr_path, out, "rgba"])
+    raw = open(out, "rb").read()
+    w, h = struct.unpack_from("<ii", raw, 0)
+    return np.frombuffer(raw, dtype=np.float32, offset=8).reshape(h, w, 4)

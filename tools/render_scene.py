@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--gmon", type=int, default=0, help="GMoN bucket count (0 = plain mean)")
     ap.add_argument("--camera-pos", type=float, nargs=3); ap.add_argument("--camera-target", type=float, nargs=3, default=(0, 0, 0))
     ap.add_argument("--focal", type=float, default=28.0)
-    ap.add_argument("--env", choices=["none", "sky"], default="none", help="add a procedural sky environment (files without one)")
+    ap.add_argument("--env", default="none", help="'sky' = procedural sky, or the path of an .exr / Radiance .hdr environment map")
     ap.add_argument("--exposure", type=float, default=0.0)
     a = ap.parse_args()
     t0 = time.time()
@@ -41,6 +41,8 @@ def main():
         sc = scene_io.SceneFile.load(a.scene) if a.scene.endswith(".json") else scene_io.SceneFile.empty().import_gltf(a.scene, scene_io.GLTF_SKIP_EMPTY_NODES)
         if a.env == "sky":
             sc.set_environment(scenes.sky_environment(1024, 512))
+        elif a.env != "none":
+            sc.load_environment(a.env)
         if a.camera_pos is not None or not sc.cameras():
             sc.add_camera(a.camera_pos or (0.0, 1.5, 6.0), a.camera_target, a.focal)
         c = sc.counts()
