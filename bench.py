@@ -184,7 +184,8 @@ def main():
         "extra": {
             "closest_rays": int(st.closest_rays), "shadow_rays": int(st.shadow_rays), "shaded_hits": int(st.shaded_hits),
             "paths": int(st.paths), "nonfinite_samples": int(st.nonfinite_samples), "mean_path_segments": round(st.closest_rays / max(1, st.paths), 3),
-            "bvh_build_ms": round(st.bvh_build_ms, 3), "bvh_nodes": int(st.bvh_nodes), "bvh_max_depth": int(st.bvh_max_depth),
+            "bvh_build_ms": round(st.bvh_build_ms, 3), "bvh_build_mtris_per_s": round(st.triangles / max(st.bvh_build_ms, 1e-9) / 1e3, 1),
+            "bvh_nodes": int(st.bvh_nodes), "bvh_depth4": int(st.bvh_max_depth),
             "upload_ms": round(st.upload_ms, 3),
             "kernel_ms": {"raygen": round(st.ms_raygen, 2), "closest": round(ms_closest, 2), "shade": round(st.ms_shade, 2),
                           "shadow": round(ms_shadow, 2), "accumulate": round(st.ms_accumulate, 2)},
