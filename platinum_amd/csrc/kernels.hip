@@ -114,41 +114,63 @@ struct ChunkClaims {
   }
 };
 
-// Lists the non-empty chunks of every segment, wave-major.  Block 0: the closest-hit queue (state buffer `cur`);
-// block 1: the shadow queue.  One block each: an exclusive scan over <= 8192 per-wave chunk counts, then every thread
-// writes the entries of its waves.
+// Lists the non-empty chunks of every segment, wave-major.  blockIdx.y = 0: the closest-hit queue (state buffer `cur`);
+// 1: the shadow queue.  kTableBlocks blocks per list, each owning a contiguous slice of the producer waves: a block first sums
+// the chunk counts of all waves before its slice (its base offset), scans its own slice in LDS, then all of its threads write
+// the slice's entries cooperatively (entry -> wave by binary search in the LDS prefix), so the stores are coalesced.  (One block
+// per list took 0.18 ms per call at 64 samples in flight — 2.5 % of a C2 step.)
+constexpr uint32_t kTableBlocks = 32;
 __global__ void __launch_bounds__(1024) k_chunk_tables(Segments seg, uint32_t cur, BatchCounters* __restrict__ ctr,
                                                         uint32_t bounce_closest, uint32_t bounce_shadow, uint32_t do_shadow) {
-  const bool sh = blockIdx.x == 1;
+  const bool sh = blockIdx.y == 1;
   if (sh && !do_shadow) return;
   const uint32_t* __restrict__ counts = sh ? seg.shadow : seg.active[cur];
   uint32_t* __restrict__ table = sh ? seg.table_shadow : seg.table_closest;
   __shared__ uint32_t part[1024];
-  const uint32_t per = (seg.nwaves + 1023u) / 1024u;  // waves per thread (<= 8)
-  const uint32_t w0 = threadIdx.x * per;
-  uint32_t mine = 0;
-  for (uint32_t i = 0; i < per; i++) {
-    const uint32_t w = w0 + i;
-    if (w < seg.nwaves) mine += (counts[w] + 63u) / 64u;
+  __shared__ uint32_t base_sh;
+  const uint32_t slice = (seg.nwaves + kTableBlocks - 1) / kTableBlocks;  // waves per block (<= 1024 for nwaves <= 32768)
+  const uint32_t w_begin = blockIdx.x * slice;
+  const uint32_t w_end = w_begin + slice < seg.nwaves ? w_begin + slice : seg.nwaves;
+  // base = chunks of all waves before this slice; the last block also learns the grand total
+  uint32_t before = 0, total = 0;
+  for (uint32_t w = threadIdx.x; w < seg.nwaves; w += 1024) {
+    const uint32_t nc = (counts[w] + 63u) / 64u;
+    total += nc;
+    if (w < w_begin) before += nc;
   }
+  part[threadIdx.x] = before;
+  __syncthreads();
+  for (uint32_t off = 512; off > 0; off >>= 1) { if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off]; __syncthreads(); }
+  if (threadIdx.x == 0) base_sh = part[0];
+  __syncthreads();
+  if (blockIdx.x == kTableBlocks - 1) {
+    part[threadIdx.x] = total;
+    __syncthreads();
+    for (uint32_t off = 512; off > 0; off >>= 1) { if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+      if (sh) ctr->chunks_shadow[bounce_shadow] = part[0];
+      else ctr->chunks_closest[bounce_closest] = part[0];
+    }
+    __syncthreads();
+  }
+  // inclusive scan of this slice's per-wave chunk counts (thread t <-> wave w_begin + t)
+  const uint32_t mine = (w_begin + threadIdx.x < w_end) ? (counts[w_begin + threadIdx.x] + 63u) / 64u : 0u;
   part[threadIdx.x] = mine;
   __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+  for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele
     const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
     __syncthreads();
     part[threadIdx.x] += v;
     __syncthreads();
   }
-  uint32_t d = part[threadIdx.x] - mine;  // exclusive prefix
-  for (uint32_t i = 0; i < per; i++) {
-    const uint32_t w = w0 + i;
-    if (w >= seg.nwaves) break;
-    const uint32_t nc = (counts[w] + 63u) / 64u;
-    for (uint32_t k = 0; k < nc; k++) table[d++] = (k << 16) | w;
-  }
-  if (threadIdx.x == 1023) {
-    if (sh) ctr->chunks_shadow[bounce_shadow] = part[1023];
-    else ctr->chunks_closest[bounce_closest] = part[1023];
+  const uint32_t n_entries = part[1023];
+  const uint32_t base = base_sh;
+  for (uint32_t e = threadIdx.x; e < n_entries; e += 1024) {
+    // first t with inclusive prefix part[t] > e
+    uint32_t lo = 0, hi = 1023;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (part[mid] > e) hi = mid; else lo = mid + 1; }
+    const uint32_t k = e - (lo ? part[lo - 1] : 0u);
+    table[base + e] = (k << 16) | (w_begin + lo);
   }
 }
 
@@ -636,7 +658,7 @@ void launch_raygen(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState
 }
 void launch_chunk_tables(hipStream_t s, Segments seg, uint32_t cur, BatchCounters* ctr, uint32_t bounce_closest,
                          uint32_t bounce_shadow, bool do_shadow) {
-  hipLaunchKernelGGL(k_chunk_tables, dim3(2), dim3(1024), 0, s, seg, cur, ctr, bounce_closest, bounce_shadow, do_shadow ? 1u : 0u);
+  hipLaunchKernelGGL(k_chunk_tables, dim3(kTableBlocks, 2), dim3(1024), 0, s, seg, cur, ctr, bounce_closest, bounce_shadow, do_shadow ? 1u : 0u);
 }
 void launch_trace_closest(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, vec4* hit, Segments seg, uint32_t cur,
                           BatchCounters* ctr, uint32_t bounce, uint32_t* spill, int32_t* hitlog, uint32_t log_stride, bool count) {
