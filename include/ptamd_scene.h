@@ -40,7 +40,7 @@ int pt_scene_import_gltf(pt_scene* s, const char* gltf_or_glb_path, int options)
  * "load environment" does: TextureLoader HDR path + Environment::setTexture). */
 int pt_scene_set_environment(pt_scene* s, const float* rgba, uint32_t width, uint32_t height, const char* name);
 /* The same from a file, as TextureLoader::loadFromFile(path, name, TextureType::HDR) (loaders/texture.cpp:86-103): ".exr" is read like
- * tinyexr's LoadEXR (scanline NONE / RLE / ZIPS / ZIP, HALF / FLOAT), anything else like stbi_loadf (Radiance .hdr). */
+ * tinyexr's LoadEXR (scanline NONE / RLE / ZIPS / ZIP / PIZ, HALF / FLOAT), anything else like stbi_loadf (Radiance .hdr). */
 int pt_scene_load_environment(pt_scene* s, const char* path);
 
 typedef struct pt_scene_counts {

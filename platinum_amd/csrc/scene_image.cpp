@@ -2,9 +2,9 @@
 // TextureType::HDR (/root/reference/src/loaders/texture.cpp:86-103): OpenEXR through tinyexr's LoadEXR, anything else
 // through stb_image's stbi_loadf (Radiance .hdr).  Both are third-party code vendored by the reference (deps/tinyexr,
 // deps/stb_image); this file restates the parts of their behaviour an environment map needs:
-//   EXR   single-part scanline files, NONE / RLE / ZIPS / ZIP compression, HALF / FLOAT / UINT channels, data-window offsets,
+//   EXR   single-part scanline files, NONE / RLE / ZIPS / ZIP / PIZ compression, HALF / FLOAT / UINT channels, data-window offsets,
 //         either line order; RGBA assembled as LoadEXR does (missing A = 1, a single channel is replicated to all four).
-//         PIZ / PXR24 / B44 / DWA and tiled or multi-part files are a loud error.
+//         PXR24 / B44 / DWA and tiled or multi-part files are a loud error.
 //   HDR   "#?RADIANCE" / "#?RGBE", -Y H +X W, flat and new-style RLE scanlines; float = mantissa * 2^(e - 136), alpha 1.
 // Pinned in tests/test_scene_ingestion.py against files written by an independent Python encoder and, where oracle/_ref was
 // built, against the reference's own tinyexr (oracle/_ref/exr2raw).
@@ -78,6 +78,193 @@ bool exr_unrle(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
   }
   return o == out.size();
 }
+
+// ---- PIZ (OpenEXR ImfPizCompressor; tinyexr.h DecompressPiz): bitmap of the 16-bit values in use, a Huffman-coded stream of the
+// range-compressed values (canonical codes of <= 58 bits, a run-length symbol), and a 2-D Haar-like wavelet per channel ----
+struct BitReader {
+  const uint8_t* p; size_t nbits, pos = 0;
+  bool ok = true;
+  uint32_t bit() { if (pos >= nbits) { ok = false; return 0; } const uint32_t b = (p[pos >> 3] >> (7 - (pos & 7))) & 1u; pos++; return b; }
+  uint32_t bits(int n) { uint32_t v = 0; for (int i = 0; i < n; i++) v = v << 1 | bit(); return v; }
+};
+
+// hufUncompress: 20-byte header (im, iM, table length, nBits, reserved), the packed code-length table, the bit stream.
+bool piz_huf_uncompress(const uint8_t* in, size_t n, std::vector<uint16_t>& out) {
+  if (n < 20) return false;
+  auto rd = [&](size_t o) { uint32_t v; memcpy(&v, in + o, 4); return v; };
+  const uint32_t im = rd(0), iM = rd(4), nbits = rd(12);
+  constexpr uint32_t kEnc = (1u << 16) + 1;
+  if (im >= kEnc || iM >= kEnc || im > iM) return false;
+  // code lengths: 6 bits each; 59..62 = a run of 2..5 zero lengths, 63 = 8 more bits: a run of 6..261
+  std::vector<uint8_t> len(kEnc, 0);
+  BitReader tb{in + 20, (n - 20) * 8};
+  for (uint32_t i = im; i <= iM; i++) {
+    const uint32_t l = tb.bits(6);
+    if (!tb.ok) return false;
+    if (l == 63) { const uint32_t run = tb.bits(8) + 6; if (i + run > iM + 1) return false; i += run - 1; }
+    else if (l >= 59) { const uint32_t run = l - 59 + 2; if (i + run > iM + 1) return false; i += run - 1; }
+    else len[i] = (uint8_t)l;
+  }
+  if (!tb.ok) return false;
+  const size_t table_bytes = (tb.pos + 7) / 8;
+  const uint8_t* data = in + 20 + table_bytes;
+  if ((size_t)nbits > (n - 20 - table_bytes) * 8) return false;
+  // canonical codes (hufCanonicalCodeTable): first code of each length from the longest up; within a length, by symbol value
+  uint64_t count[59] = {0}, first[59] = {0};
+  for (uint32_t i = 0; i < kEnc; i++) count[len[i]]++;
+  {
+    uint64_t c = 0;
+    for (int l = 58; l > 0; l--) { const uint64_t nc = (c + count[l]) >> 1; first[l] = c; c = nc; }
+  }
+  std::vector<uint32_t> offset(60, 0), sorted;
+  sorted.reserve(kEnc);
+  for (int l = 1; l <= 58; l++) {
+    offset[l] = (uint32_t)sorted.size();
+    if (count[l]) for (uint32_t i = im; i <= iM; i++) if (len[i] == l) sorted.push_back(i);
+  }
+  // a 12-bit table for the short codes, bit-serial continuation for the long ones
+  constexpr int kFast = 12;
+  std::vector<uint32_t> fast(1u << kFast, 0);  // (symbol << 6) | length, 0 = none
+  for (int l = 1; l <= kFast; l++)
+    for (uint64_t k = 0; k < count[l]; k++) {
+      const uint64_t code = first[l] + k;
+      const uint32_t sym = sorted[offset[l] + (uint32_t)k];
+      for (uint32_t fill = 0; fill < (1u << (kFast - l)); fill++) fast[(size_t)((code << (kFast - l)) | fill)] = sym << 6 | (uint32_t)l;
+    }
+  BitReader br{data, nbits};
+  size_t o = 0;
+  const uint32_t rlc = iM;
+  while (br.pos < br.nbits) {
+    uint32_t sym = ~0u;
+    if (br.nbits - br.pos >= (size_t)kFast) {
+      uint32_t peek = 0;
+      for (int i = 0; i < kFast; i++) { const size_t q = br.pos + i; peek = peek << 1 | ((br.p[q >> 3] >> (7 - (q & 7))) & 1u); }
+      const uint32_t e = fast[peek];
+      if (e) { sym = e >> 6; br.pos += e & 63u; }
+    }
+    if (sym == ~0u) {
+      uint64_t code = 0;
+      for (int l = 1; l <= 58 && sym == ~0u; l++) {
+        code = code << 1 | br.bit();
+        if (!br.ok) return false;
+        if (count[l] && code >= first[l] && code - first[l] < count[l]) sym = sorted[offset[l] + (uint32_t)(code - first[l])];
+      }
+      if (sym == ~0u) return false;
+    }
+    if (sym == rlc) {
+      const uint32_t run = br.bits(8);
+      if (!br.ok || o == 0 || o + run > out.size()) return false;
+      for (uint32_t k = 0; k < run; k++, o++) out[o] = out[o - 1];
+    } else {
+      if (o >= out.size()) return false;
+      out[o++] = (uint16_t)sym;
+    }
+  }
+  return o == out.size();
+}
+
+inline void wdec14(uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) {
+  const int ls = (int16_t)l, hs = (int16_t)h;
+  const int ai = ls + (hs & 1) + (hs >> 1);
+  a = (uint16_t)(int16_t)ai;
+  b = (uint16_t)(int16_t)(ai - hs);
+}
+inline void wdec16(uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) {
+  const int m = l, d = h;
+  const int bb = (m - (d >> 1)) & 0xffff;
+  const int aa = (d + bb - 0x8000) & 0xffff;
+  b = (uint16_t)bb;
+  a = (uint16_t)aa;
+}
+// wav2Decode: in-place inverse transform of an nx x ny plane with element strides ox / oy
+void piz_wav2_decode(uint16_t* in, int nx, int ox, int ny, int oy, uint16_t mx) {
+  const bool w14 = mx < (1 << 14);
+  const int n = nx > ny ? ny : nx;
+  int p = 1;
+  while (p <= n) p <<= 1;
+  p >>= 1;
+  int p2 = p;
+  p >>= 1;
+  auto dec = [&](uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) { if (w14) wdec14(l, h, a, b); else wdec16(l, h, a, b); };
+  while (p >= 1) {
+    uint16_t* py = in;
+    uint16_t* const ey = in + (ptrdiff_t)oy * (ny - p2);
+    const ptrdiff_t oy1 = (ptrdiff_t)oy * p, oy2 = (ptrdiff_t)oy * p2, ox1 = (ptrdiff_t)ox * p, ox2 = (ptrdiff_t)ox * p2;
+    uint16_t i00, i01, i10, i11;
+    for (; py <= ey; py += oy2) {
+      uint16_t* px = py;
+      uint16_t* const ex = py + (ptrdiff_t)ox * (nx - p2);
+      for (; px <= ex; px += ox2) {
+        uint16_t* p01 = px + ox1; uint16_t* p10 = px + oy1; uint16_t* p11 = p10 + ox1;
+        dec(*px, *p10, i00, i10);
+        dec(*p01, *p11, i01, i11);
+        dec(i00, i01, *px, *p01);
+        dec(i10, i11, *p10, *p11);
+      }
+      if (nx & p) {  // odd column
+        uint16_t* p10 = px + oy1;
+        dec(*px, *p10, i00, *p10);
+        *px = i00;
+      }
+    }
+    if (ny & p) {  // odd line
+      uint16_t* px = py;
+      uint16_t* const ex = py + (ptrdiff_t)ox * (nx - p2);
+      for (; px <= ex; px += ox2) {
+        uint16_t* p01 = px + ox1;
+        dec(*px, *p01, i00, *p01);
+        *px = i00;
+      }
+    }
+    p2 = p;
+    p >>= 1;
+  }
+}
+
+// One PIZ block -> the raw block layout (per scanline, channels in file order, planar)
+bool piz_decompress(const uint8_t* in, size_t n, const std::vector<Channel>& channels, int width, int lines, std::vector<uint8_t>& raw) {
+  if (n < 4) return false;
+  uint16_t min_nz, max_nz;
+  memcpy(&min_nz, in, 2); memcpy(&max_nz, in + 2, 2);
+  constexpr size_t kBitmap = 65536 / 8;
+  std::vector<uint8_t> bitmap(kBitmap, 0);
+  size_t p = 4;
+  if (max_nz >= kBitmap) return false;
+  if (min_nz <= max_nz) {
+    const size_t len = (size_t)max_nz - min_nz + 1;
+    if (p + len > n) return false;
+    memcpy(&bitmap[min_nz], in + p, len);
+    p += len;
+  } else if (!(min_nz == kBitmap - 1 && max_nz == 0)) return false;  // (all-zero block)
+  std::vector<uint16_t> lut(65536, 0);
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < 65536; i++) if (i == 0 || (bitmap[i >> 3] & (1u << (i & 7)))) lut[k++] = (uint16_t)i;
+  const uint16_t max_value = (uint16_t)(k - 1);
+  if (p + 4 > n) return false;
+  int32_t length;
+  memcpy(&length, in + p, 4);
+  p += 4;
+  if (length < 0 || p + (size_t)length > n) return false;
+  std::vector<uint16_t> tmp(raw.size() / 2);
+  if (!piz_huf_uncompress(in + p, (size_t)length, tmp)) return false;
+  std::vector<size_t> start(channels.size());
+  size_t off = 0;
+  for (size_t c = 0; c < channels.size(); c++) {
+    const int size = channels[c].type == 1 ? 1 : 2;  // 16-bit words per pixel
+    start[c] = off;
+    for (int j = 0; j < size; j++) piz_wav2_decode(&tmp[off + (size_t)j], width, size, lines, width * size, max_value);
+    off += (size_t)width * lines * size;
+  }
+  for (auto& v : tmp) v = lut[v];
+  uint8_t* dst = raw.data();
+  for (int y = 0; y < lines; y++)
+    for (size_t c = 0; c < channels.size(); c++) {
+      const size_t words = (size_t)width * (channels[c].type == 1 ? 1 : 2);
+      memcpy(dst, &tmp[start[c] + (size_t)y * words], words * 2);
+      dst += words * 2;
+    }
+  return true;
+}
 }  // namespace
 
 std::vector<float> read_exr_rgba(const std::string& path, uint32_t* w_out, uint32_t* h_out) {
@@ -120,11 +307,11 @@ std::vector<float> read_exr_rgba(const std::string& path, uint32_t* w_out, uint3
     p += size;
   }
   if (channels.empty() || compression < 0 || dw[2] < dw[0] || dw[3] < dw[1]) fail("exr: incomplete header");
-  if (compression > 3) fail("exr: compression " + std::to_string(compression) + " (PIZ / PXR24 / B44 / DWA) is not supported: re-save as ZIP");
+  if (compression > 4) fail("exr: compression " + std::to_string(compression) + " (PXR24 / B44 / DWA) is not supported: re-save as ZIP or PIZ");
   if (line_order > 1) fail("exr: random-y line order is not supported");
   const int64_t W = (int64_t)dw[2] - dw[0] + 1, H = (int64_t)dw[3] - dw[1] + 1;
   if (W <= 0 || H <= 0 || W > 65536 || H > 65536) fail("exr: bad data window");
-  const int lines_per_block = compression == 3 ? 16 : 1;
+  const int lines_per_block = compression == 3 ? 16 : (compression == 4 ? 32 : 1);
   const size_t nblocks = (size_t)((H + lines_per_block - 1) / lines_per_block);
   size_t bytes_per_line = 0;
   std::vector<size_t> ch_off(channels.size());
@@ -158,6 +345,8 @@ std::vector<float> read_exr_rgba(const std::string& path, uint32_t* w_out, uint3
       uLongf len = (uLongf)raw.size();
       if (uncompress(raw.data(), &len, src, csize) != Z_OK || len != raw.size()) fail("exr: bad zlib data");
       exr_unpredict(raw);
+    } else if (compression == 4) {
+      if (!piz_decompress(src, csize, channels, (int)W, lines, raw)) fail("exr: bad PIZ data");
     } else fail("exr: block size does not match an uncompressed file");
     for (int l = 0; l < lines; l++) {
       const uint8_t* line = &raw[bytes_per_line * (size_t)l];

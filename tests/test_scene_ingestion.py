@@ -550,3 +550,45 @@ def test_radiance_hdr_environment_reader(tmp_path, rle):
     sc2.load_environment(path)
     o = oracle_lib.OracleScene(sc2, make_params(32, 18, 1, 3))
     assert o.constants().envLightCount == 1 and np.isfinite(o.debug_sample(0)[0]).all()
+
+
+EXRWRITE_PATH = os.path.join(sf.ROOT, "oracle", "_ref", "exrwrite")
+
+
+@pytest.mark.skipif(not (os.path.exists(EXRWRITE_PATH) and os.path.exists(sf.EXR2RAW_PATH)), reason="oracle/_ref (reference tinyexr) not built")
+@pytest.mark.parametrize("comp,ptype,chans,shape", [("piz", "half", 3, (70, 51)), ("piz", "float", 4, (33, 64)), ("piz", "half", 1, (40, 40)),
+                                                     ("piz", "half", 4, (5, 3)), ("zip", "half", 3, (70, 51)), ("rle", "float", 3, (20, 31))])
+def test_exr_files_written_by_the_reference_tinyexr(tmp_path, comp, ptype, chans, shape):
+    """Files ENCODED by the reference's own tinyexr (oracle/_ref/exrwrite) — the only PIZ encoder here — read by the product and by
+    the reference's LoadEXR to the same bits.  Smooth + noisy + constant content: both wavelet modes (14 / 16 bit), Huffman
+    run-length codes and long codes get exercised."""
+    import subprocess
+    h, w = shape
+    rng = np.random.default_rng(h * 131 + w)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([np.sin(xx * 0.2) * 3 + 4, (yy * xx) % 7 * 0.5, rng.random((h, w)) * (60000.0 if ptype == "half" else 1e6), np.full((h, w), 0.75)], -1)[..., :chans]
+    img[: h // 3, : w // 2] = 1.5   # a constant region -> run-length codes
+    img = np.ascontiguousarray(img, dtype=f32)
+    raw = str(tmp_path / "in.f32"); path = str(tmp_path / "t.exr")
+    img.tofile(raw)
+    subprocess.check_call([EXRWRITE_PATH, raw, str(w), str(h), str(chans), ptype, comp, path])
+    sc = scene_io.SceneFile.empty()
+    sc.load_environment(path)
+    sc.add_camera((0, 0, 3), (0, 0, 0))
+    got = _env_pixels(sc)
+    ref = sf.tinyexr_reference_rgba(path, str(tmp_path))
+    assert got.shape == (h, w, 4) and got.tobytes() == ref.tobytes()
+    want = img.astype(np.float16).astype(f32) if ptype == "half" else img
+    if chans >= 3:
+        assert np.array_equal(got[..., :3], want[..., :3])
+    else:
+        assert np.array_equal(got[..., 0], want[..., 0]) and np.array_equal(got[..., 3], want[..., 0])
+
+
+def test_committed_piz_fixture():
+    """tests/golden/exr_piz_fixture.exr (minted by tools/make_golden.py through the reference's tinyexr encoder) + its pixels."""
+    g = np.load(os.path.join(G, "exr_piz_fixture.npz"))
+    sc = scene_io.SceneFile.empty()
+    sc.load_environment(os.path.join(G, "exr_piz_fixture.exr"))
+    sc.add_camera((0, 0, 3), (0, 0, 0))
+    assert _env_pixels(sc).tobytes() == g["rgba"].tobytes()

@@ -13,6 +13,8 @@ as small fixtures under tests/golden/.  Re-running must reproduce the files bit-
   mikkt_tangents.npz      tangents of five meshes computed by the REFERENCE's deps/mikkt/mikktspace.c (compiled where it lies into
                           oracle/_ref/libmikkt.so) through the callbacks of core/mesh.cpp:11-57
   scene_fixture/mini.*    a scene.json + _data.bin pair in the reference's format (tests/scene_formats.py restates saveToFile)
+  exr_piz_fixture.exr/npz a 96x48 RGB half PIZ OpenEXR ENCODED by the reference's tinyexr (oracle/_ref/exrwrite) and the RGBA floats its
+                          LoadEXR decodes from it (oracle/_ref/exr2raw)
   n3_textured_golden.npz  scenes.textured_scene() (textures, normal map, cut-outs, environment), 96x54, 6 bounces: accumulator
                           at 2 spp, per-bounce hit ids of sample 0, the environment alias table
 """
@@ -79,5 +81,16 @@ else:
 os.makedirs(os.path.join(G, "scene_fixture"), exist_ok=True)
 assets, root, envmap, _ = tsi.mini_scene_spec()
 sf.write_reference_scene(os.path.join(G, "scene_fixture", "mini.json"), assets, root, envmap)
+# ---- N4: a PIZ-compressed OpenEXR written by the reference's tinyexr (oracle/_ref/exrwrite) and what its LoadEXR reads back ----
+exrwrite, exr2raw = os.path.join(ROOT, "oracle", "_ref", "exrwrite"), os.path.join(ROOT, "oracle", "_ref", "exr2raw")
+if os.path.exists(exrwrite) and os.path.exists(exr2raw):
+    import subprocess, tempfile
+    env = scenes.sky_environment(96, 48, sun=(30, 9), sun_radiance=300.0)[..., :3].copy()
+    with tempfile.TemporaryDirectory() as td:
+        env.astype(np.float32).tofile(os.path.join(td, "in.f32"))
+        subprocess.check_call([exrwrite, os.path.join(td, "in.f32"), "96", "48", "3", "half", "piz", os.path.join(G, "exr_piz_fixture.exr")])
+        np.savez_compressed(os.path.join(G, "exr_piz_fixture.npz"), rgba=sf.tinyexr_reference_rgba(os.path.join(G, "exr_piz_fixture.exr"), td))
+else:
+    print("oracle/_ref/exrwrite not built: exr_piz_fixture left as is")
 for f in sorted(os.listdir(G)):
     print(f, os.path.getsize(os.path.join(G, f)))
