@@ -226,45 +226,19 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DeviceScene S, PathState st, 
 // exhausted with nobody else able to advance), every lane with a queued leaf runs ONE triangle test.  The triangle code
 // therefore executes with most lanes busy instead of whenever a single lane met a leaf.  A ray is finished when its node
 // stack is exhausted and its queue is empty (any-hit: on the first accepted hit).
-#ifndef PT_FULL_LANES
-#define PT_FULL_LANES 64  /* lanes with a full queue needed to force a triangle round = 64 / PT_FULL_LANES */
-#endif
-#ifndef PT_GO_NUM
-#define PT_GO_NUM 1
-#define PT_GO_DEN 2
-#endif
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void wave_traverse(const DeviceScene& S, TravState& ts, TraversalCount* tc) {
-#ifdef PT_WAVE_COUNT
-  // instrumentation build (tools/sweep_variants.sh): nodes += lanes holding a ray in this iteration, tris += lanes of
-  // them that cannot visit a node (PT_WAVE_COUNT == 1: draining = node stack exhausted, leaves queued; == 2: queue full)
-  TraversalCount dummy;
-  const bool donode = ts.cur != kInvalidRef && ts.st.npend <= kPendLeaves - 4;
-  if (COUNT) {
-    tc->nodes += 1;
-    if (PT_WAVE_COUNT == 1 && ts.cur == kInvalidRef && ts.st.npend > 0) tc->tris += 1;
-    if (PT_WAVE_COUNT == 2 && ts.cur != kInvalidRef && !donode) tc->tris += 1;
-    if (PT_WAVE_COUNT == 3) { const bool first = (int)__builtin_ctzll(__ballot(1)) == (int)(threadIdx.x & 63); if (first) tc->tris += 64; }
-  }
-  if (donode) trav_node<false>(S, ts, &dummy);
-#else
   if (ts.cur != kInvalidRef && ts.st.npend <= kPendLeaves - 4) trav_node<COUNT>(S, ts, tc);
-#endif
   const bool pending = ts.st.npend > 0;
   const bool stuck = pending && (ts.cur == kInvalidRef || ts.st.npend > kPendLeaves - 4);
   const bool advancing = ts.cur != kInvalidRef && !stuck;
   const unsigned long long mp = __ballot(pending);
   if (mp == 0) return;
-  const bool go = PT_GO_DEN * __popcll(mp) >= PT_GO_NUM * __popcll(__ballot(1)) || PT_FULL_LANES * __popcll(__ballot(ts.st.npend > kPendLeaves - 4)) >= 64 || __ballot(advancing) == 0;
-#ifdef PT_WAVE_COUNT
-  if (go && pending) {
-    if (trav_pending_leaf<ANY, false>(S, ts, &dummy)) { ts.cur = kInvalidRef; ts.st.npend = 0; ts.st.sp = 0; }
-  }
-#else
+  // triangle round when half of the lanes holding a ray have a queued leaf, a lane's queue is full, or nobody can advance
+  const bool go = 2 * __popcll(mp) >= __popcll(__ballot(1)) || __ballot(ts.st.npend > kPendLeaves - 4) != 0 || __ballot(advancing) == 0;
   if (go && pending) {
     if (trav_pending_leaf<ANY, COUNT>(S, ts, tc)) { ts.cur = kInvalidRef; ts.st.npend = 0; ts.st.sp = 0; }
   }
-#endif
 }
 
 // ---- closest hit ---------------------------------------------------------------------------------------------------

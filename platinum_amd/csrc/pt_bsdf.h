@@ -410,11 +410,7 @@ struct BSDF {
   PT_HD BsdfSample sampleOpaque(vec3 wo, vec3 r) const {  // bsdf.metal:626-684
     const float F_avg = avgDielectricFresnelFit(ctx.ior);
     const float blendingFactor = opaqueDielectricFactor(wo, F_avg);
-#ifdef PT_EXP_NO_OPAQUE_SPEC  // timing experiment only: what does the rarely taken specular branch of the opaque lobe cost?
-    if (false) {
-#else
     if (r.z < blendingFactor) {
-#endif
       if (ggx.isSmooth()) {
         const float fresnel_ss = fresnel(fabsf(wo.z), ctx.ior);
         const vec3 wi = v3(-wo.x, -wo.y, wo.z);

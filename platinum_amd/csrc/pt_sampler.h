@@ -26,9 +26,6 @@ PT_HD uint32_t pcg4d_x(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
 PT_HD uint32_t halton_offset(uint32_t px, uint32_t py, uint32_t sample) { return pcg4d_x(px, py, sample, px + py); }
 
 PT_HD float halton(const HaltonEntry* __restrict__ tab, uint32_t i, uint32_t d) {
-#ifdef PT_FAKE_HALTON  // timing experiment only: NOT the reference's sequence
-  return (float)((i * 2654435761u + d * 40503u) >> 8) * (1.0f / 16777216.0f);
-#endif
   const HaltonEntry e = tab[d];
   float f = 1.0f;
   float r = 0.0f;

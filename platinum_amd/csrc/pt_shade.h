@@ -235,13 +235,7 @@ PT_HD ShadeOut stage_shade(const DeviceScene& S, const ShadeIn& in) {
   vec2 rc = {0.0f, 0.0f};
   if (ctx.clearcoat > 0.0f) rc = halton.sample2d(); else halton.dim += 2;
   const BSDF bsdf(ctx, S.flags, S.luts, wo);
-#ifdef PT_EXP_NO_SAMPLE  // timing experiment only: cosine-weighted diffuse sample instead of the principled lobes
-  BsdfSample sample;
-  sample.wi = sampleCosineHemisphere(vec2{r01.x, r01.y}); sample.f = ctx.albedo * (1.0f / kPi); sample.Le = ctx.emission;
-  sample.pdf = sample.wi.z * (1.0f / kPi); sample.flags = Sample_Reflected | Sample_Diffuse | ((ctx.flags & PT_MATERIAL_EMISSIVE) ? Sample_Emitted : 0);
-#else
   const BsdfSample sample = bsdf.sample(wo, vec4{r01.x, r01.y, r2, r3}, rc);
-#endif
 
   // ---- light hit (kernel.metal:560-576; :325-327 for the simple integrator) ----
   if (sample.flags & Sample_Emitted) {
@@ -294,11 +288,7 @@ PT_HD ShadeOut stage_shade(const DeviceScene& S, const ShadeIn& in) {
       }
 
       const vec3 wi = frame.worldToLocal(lwi);
-#ifdef PT_EXP_NO_NEE_EVAL  // timing experiment only: what does the NEE evaluation cost?
-      const BsdfEval ev{v3(0.01f * wi.z), 0.5f};
-#else
       const BsdfEval ev = bsdf.eval(wo, wi);
-#endif
       if (length_squared(ev.f) > 0.0f) {
         // `ir` payload of the shadow ray (kernel.metal:625): only evaluated when an alpha test can consume it
         out.shadow_payload = S.has_alpha ? halton.sample1d() : (halton.dim++, 0.0f);

@@ -427,21 +427,21 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
 
   // ---- acceleration structure (replaces rebuildAccelerationStructures, renderer_pt.cpp:653-749) ----
   {
-    hipEvent_t e0, e1;
-    PT_HIP(hipEventCreate(&e0));
-    PT_HIP(hipEventCreate(&e1));
-    PT_HIP(hipEventRecord(e0, r->stream));
+    struct EventPair {  // destroyed on every path out of this block
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev;
+    PT_HIP(hipEventCreate(&ev.e0));
+    PT_HIP(hipEventCreate(&ev.e1));
+    PT_HIP(hipEventRecord(ev.e0, r->stream));
     hipError_t be = build_lbvh(r->stream, S, r->instance_count, r->tri_count, (uint32_t)(kLdsStack + kSpillStack), &r->bvh);
-    if (be != hipSuccess) {
-      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (be != hipSuccess)
       return fail(be == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP, std::string("LBVH build failed: ") + hipGetErrorString(be));
-    }
-    PT_HIP(hipEventRecord(e1, r->stream));
-    PT_HIP(hipEventSynchronize(e1));
+    PT_HIP(hipEventRecord(ev.e1, r->stream));
+    PT_HIP(hipEventSynchronize(ev.e1));
     float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, ev.e0, ev.e1);
     r->bvh_ms = ms;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     // traversal stack: <= 3 pushes per 4-wide level; 4-wide depth = ceil(binary depth / 2)
     if (r->bvh.depth4 * 3 > (uint32_t)(kLdsStack + kSpillStack))
       return fail(PT_ERR_UNSUPPORTED, "BVH too deep for the traversal stack (degenerate geometry: thousands of coincident triangles?)");
@@ -474,6 +474,8 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
   // the trace kernels claim chunks from a table, so their grid is free: as many blocks as their LDS / VGPR budget keeps resident
   r->trace_grid = (uint32_t)r->num_cu * r->trace_blocks_per_cu;
   r->nwaves = r->grid * (kBlock / 64);
+  // k_chunk_tables packs the wave id into 16 bits ((k << 16) | w) and scans a slice of <= 1024 waves per table block
+  if (r->nwaves > 32768) return fail(PT_ERR_UNSUPPORTED, "persistent grid too large for the chunk tables (num_cu * blocks_per_cu * 4 waves must be <= 32768)");
   {
     const uint64_t tiles = (uint64_t)((p->width + 7) / 8) * ((p->height + 7) / 8);
     const uint64_t per_wave = (tiles + r->nwaves - 1) / r->nwaves;  // a wave owns floor or ceil(tiles / nwaves) adjacent tiles

@@ -116,6 +116,10 @@ bool piz_huf_uncompress(const uint8_t* in, size_t n, std::vector<uint16_t>& out)
     uint64_t c = 0;
     for (int l = 58; l > 0; l--) { const uint64_t nc = (c + count[l]) >> 1; first[l] = c; c = nc; }
   }
+  // A length table that is not a prefix code (over-subscribed: more codes of length l than l bits can hold) must be rejected
+  // here — tinyexr's hufBuildDecTable does ("code needs more than l bits") — or the table fill below would leave its bounds.
+  for (int l = 1; l <= 58; l++)
+    if (count[l] && ((first[l] + count[l] - 1) >> l) != 0) return false;
   std::vector<uint32_t> offset(60, 0), sorted;
   sorted.reserve(kEnc);
   for (int l = 1; l <= 58; l++) {
@@ -129,7 +133,9 @@ bool piz_huf_uncompress(const uint8_t* in, size_t n, std::vector<uint16_t>& out)
     for (uint64_t k = 0; k < count[l]; k++) {
       const uint64_t code = first[l] + k;
       const uint32_t sym = sorted[offset[l] + (uint32_t)k];
-      for (uint32_t fill = 0; fill < (1u << (kFast - l)); fill++) fast[(size_t)((code << (kFast - l)) | fill)] = sym << 6 | (uint32_t)l;
+      const size_t base = (size_t)(code << (kFast - l));
+      if (base + (1u << (kFast - l)) > fast.size()) return false;  // cannot happen after the prefix-code check; kept as a guard
+      for (uint32_t fill = 0; fill < (1u << (kFast - l)); fill++) fast[base | fill] = sym << 6 | (uint32_t)l;
     }
   BitReader br{data, nbits};
   size_t o = 0;

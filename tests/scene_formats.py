@@ -340,6 +340,42 @@ def write_exr(path, channels, compression="zip", pixel_type="float", data_window
         f.write(hdr + table + body)
 
 
+def write_exr_blocks(path, names, w, h, pixel_type, comp_code, lines_per_block, blocks):
+    """A single-part scanline OpenEXR whose (already encoded) block payloads are given by the caller — for crafted / malformed inputs."""
+    ptype = {"half": 1, "float": 2}[pixel_type]
+
+    def attr(name, typ, data):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(data)) + data
+
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<IB3xII", ptype, 0, 1, 1) for n in sorted(names)) + b"\0"
+    win = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    hdr = struct.pack("<II", 20000630, 2)
+    hdr += attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([comp_code]))
+    hdr += attr("dataWindow", "box2i", win) + attr("displayWindow", "box2i", win) + attr("lineOrder", "lineOrder", bytes([0]))
+    hdr += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0))
+    hdr += attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    starts = list(range(0, h, lines_per_block))
+    assert len(starts) == len(blocks)
+    pos = len(hdr) + 8 * len(starts)
+    table, body = b"", b""
+    for y, blk in zip(starts, blocks):
+        table += struct.pack("<Q", pos)
+        chunk = struct.pack("<iI", y, len(blk)) + blk
+        body += chunk
+        pos += len(chunk)
+    with open(path, "wb") as f:
+        f.write(hdr + table + body)
+
+
+def piz_block_with_code_lengths(lengths, nbits=8, payload=b"\0"):
+    """A PIZ block whose Huffman code-length table holds `lengths` for symbols 0..len-1 (6 bits each, hufUnpackEncTable layout)."""
+    bits = "".join(format(l, "06b") for l in lengths)
+    bits += "0" * (-len(bits) % 8)
+    table = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+    huf = struct.pack("<IIIII", 0, len(lengths) - 1, len(table), nbits, 0) + table + payload
+    return struct.pack("<HH", 0, 0) + b"\x01" + struct.pack("<i", len(huf)) + huf
+
+
 def write_radiance_hdr(path, rgbe, rle=True):
     """rgbe: (H, W, 4) uint8.  New-style RLE scanlines (per channel) or flat."""
     h, w, _ = rgbe.shape

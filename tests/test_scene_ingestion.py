@@ -592,3 +592,47 @@ def test_committed_piz_fixture():
     sc.load_environment(os.path.join(G, "exr_piz_fixture.exr"))
     sc.add_camera((0, 0, 3), (0, 0, 0))
     assert _env_pixels(sc).tobytes() == g["rgba"].tobytes()
+
+
+def _malformed_piz_files(tmp_path):
+    """PIZ blocks whose Huffman length tables are not prefix codes (over-subscribed), which tinyexr's hufBuildDecTable rejects."""
+    out = []
+    for k, lengths in enumerate([[1, 1, 1, 1], [1, 1, 1], [2, 2, 2, 2, 2], [12] * 4097 + [0], [13, 1, 1, 1]]):
+        path = str(tmp_path / f"bad_piz_{k}.exr")
+        sf.write_exr_blocks(path, ["Y"], 8, 1, "half", 4, 32, [sf.piz_block_with_code_lengths(lengths)])
+        out.append(path)
+    return out
+
+
+def test_piz_huffman_rejects_tables_that_are_not_prefix_codes(tmp_path):
+    """an over-subscribed code-length table (three symbols of length 1 ...) used to index past the 4096-entry decode
+    table.  The environment loader must fail cleanly, as the reference's tinyexr does."""
+    for path in _malformed_piz_files(tmp_path):
+        sc = scene_io.SceneFile.empty()
+        with pytest.raises(abi.PtamdError, match="PIZ"):
+            sc.load_environment(path)
+
+
+def test_piz_huffman_malformed_tables_under_address_sanitizer(tmp_path):
+    """The same inputs through a CPU AddressSanitizer build of scene_image.cpp (sanitizers run on the CPU build only)."""
+    src = os.path.join(os.path.dirname(__file__), "..", "platinum_amd", "csrc")
+    main = tmp_path / "asan_main.cpp"
+    main.write_text(
+        '#include "scene_io.h"\n#include <cstdio>\n#include <stdexcept>\n'
+        'int main(int argc, char** argv) { int bad = 0; for (int i = 1; i < argc; i++) { uint32_t w, h; '
+        'try { (void)ptio::read_exr_rgba(argv[i], &w, &h); printf("decoded %s\\n", argv[i]); } '
+        'catch (const std::runtime_error& e) { printf("rejected: %s\\n", e.what()); bad++; } } return bad == argc - 1 ? 0 : 3; }\n')
+    exe = str(tmp_path / "asan_exr")
+    import subprocess
+    cc = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I", src,
+                         "-I", os.path.join(src, "..", "..", "include"), str(main), os.path.join(src, "scene_image.cpp"), "-lz", "-o", exe],
+                        capture_output=True, text=True)
+    if cc.returncode != 0 and "asan" in cc.stderr.lower():
+        pytest.skip("libasan not installed")
+    assert cc.returncode == 0, cc.stderr
+    files = _malformed_piz_files(tmp_path) + [os.path.join(G, "exr_piz_fixture.exr")]
+    run = subprocess.run([exe] + files[:-1], capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout + run.stderr       # every malformed file rejected, no sanitizer report
+    assert "AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr
+    good = subprocess.run([exe, files[-1]], capture_output=True, text=True)
+    assert "decoded" in good.stdout and "AddressSanitizer" not in good.stderr, good.stdout + good.stderr
