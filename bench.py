@@ -1,32 +1,53 @@
 #!/usr/bin/env python3
 """bench.py — Msamples/s of the MI355X wavefront path tracer on BASELINE.json's configs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c1] [--spp-per-step S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c1|c5] [--spp-per-step S] [--inproc]
 
 One "step" = one pass of the hot path over one batch: S samples per pixel of the whole frame (raygen ->
-{closest-hit, shade/BSDF/NEE, shadow} x bounces -> accumulate).  Default: C2 (Cornell + GGX dielectric sphere,
-1920x1080, 8 bounces), S = 8, K = 32  => the full 256 spp of BASELINE.json configs[1].
+{closest-hit, shade/BSDF/NEE, shadow} x bounces -> accumulate).  Default workload: C3 (BASELINE.json configs[2]: the
+1.04 M-triangle instanced field, 1920x1080, 8 bounces — the largest single-GPU configuration and the one the
+north-star targets are written on), S = 64, K = 8, W = 2.  `--workload c2` = configs[1].
 Metric: Msamples/s = W*H*spp*B / t / 1e6, B = configured max bounces.
 
-N > 1 (launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`): one process per GPU;
-rank g renders the same frame for sample indices [g*K*S, (g+1)*K*S) — independent-sample sharding, no exchange
-while rendering — then ONE RCCL all-reduce (sum) of the float accumulator over xGMI inside the timed region.
-Weak scaling: per-GPU work is fixed.
+N > 1: one process per GPU.  Either launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment) or, when started as a plain `python bench.py --gpus N`, this process
+starts exactly that launcher as a CHILD process before it touches torch or the GPU, relays rank 0's JSON line and exits
+with the child's code.  Rank g renders the same frame for sample indices [g*K*S, (g+1)*K*S) — independent-sample
+sharding, no exchange while rendering — then ONE RCCL all-reduce (sum) of the float accumulator over xGMI inside the
+timed region.  Weak scaling: per-GPU work is fixed.  `--inproc` instead drives all N devices from ONE process through the
+library's own multi-device entry (pt_create with a device list; host thread + stream per device; ncclAllReduce inside).
 
-Printed by rank 0: ONE JSON line (contract in the task statement) with `roofline` (closest-hit traversal kernel,
-HBM-bound accounting) and, at N = 1, `cpu_baseline` (the CPU oracle on the host cores, bounded sample).
+The timed region runs with per-kernel timing OFF; kernel times come from a second, separately timed pass of the same
+steps with HIP events around every launch (on the renderer's stream).  Rank 0 prints ONE JSON line with
+  roofline          the kernel with the largest device time, against every ceiling that could bind it
+  roofline_kernels  the same block for each hot kernel (k_shade, k_trace_closest, k_trace_shadow)
+  cpu_baseline      (N = 1) the CPU oracle on the host cores, bounded sample of the same workload
+Ceilings (MI355X_MICROARCH.md): HBM 8.0 TB/s; L2 34.5 TB/s aggregate; VALU issue 256 CU x 4 SIMD x 32 lanes x 2.4 GHz =
+78.6 T lane-ops/s.  Algorithmic bytes follow SURVEY §8(d); counter-based bytes and VALU instruction counts per work item
+come from the committed rocprofv3 --pmc passes of this same command (profiles/r02_pmc_<workload>.json, tools/profile_round.sh),
+labelled with their source — they are not measured by this run.
 """
 import argparse
-import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+L2_PEAK_GBS = 34500.0       # aggregate over the 8 XCD L2s
+VALU_PEAK_TLOPS = 78.6432   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz, in 1e12 lane-ops/s
+HBM_TARGET_FRAC = 0.40      # north_star: ">= 40 % of HBM peak on the traversal kernel"
+
+WORKLOADS = {
+    "c1": "C1 Cornell box 512x512",
+    "c2": "C2 Cornell box + GGX dielectric sphere (6144 tris), 1920x1080",
+    "c3": "C3 1.04M-triangle instanced sphere field, 1920x1080",
+    "c5": "C5 procedural Sponza-class atrium (258k tris, textures, cut-outs, 4096x2048 environment), 3840x2160",
+}
 
 
 def algorithmic_bytes_closest(nodes_per_ray, tris_per_ray):
@@ -38,26 +59,133 @@ def algorithmic_bytes_shadow(nodes_per_ray, tris_per_ray):
     return 32.0 + 4.0 + 64.0 * nodes_per_ray + 36.0 * tris_per_ray
 
 
-def main():
+# SURVEY §8(d) per shaded hit: 368 B geometry/material gather + 64 B state in + 64 B state out + <= 112 B LUT taps + 48 B light
+# record + 3 x 16 B shadow entry
+ALGORITHMIC_BYTES_SHADE = 368.0 + 64.0 + 64.0 + 112.0 + 48.0 + 48.0
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5"])
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline sample")
+    ap.add_argument("--inproc", action="store_true", help="N > 1: one process, the library's own multi-device path")
+    ap.add_argument("--pmc-pass", action="store_true",
+                    help="under rocprofv3 --pmc: only full-size batches (no warm-up, no instrumented sample, no CPU leg, no event timing)")
+    ap.add_argument("--no-kernel-pass", action="store_true", help="skip the second (event-timed) pass")
+    return ap.parse_args(argv)
 
-    import numpy as np
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as fresh child processes.  Nothing in THIS process has
+    imported torch or touched the GPU (a process that has initialised the GPU must never exec or fork GPU work)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line)
+    else:
+        sys.stdout.write(p.stdout)
+    return p.returncode if line is not None or p.returncode != 0 else 1
+
+
+def load_pmc_profile(workload):
+    """Per-work-item counter figures of the committed rocprofv3 --pmc passes (tools/profile_round.sh + tools/summarize_prof.py)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % workload)
+    if not os.path.exists(path):
+        return None, None
+    try:
+        return json.load(open(path)), os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
+
+
+def library_sha16():
+    import hashlib
+    from platinum_amd import abi
+    try:
+        return hashlib.sha256(open(abi.library_path(), "rb").read()).hexdigest()[:16]
+    except Exception:
+        return None
+
+
+def kernel_block(name, items, item_name, ms, launches, alg_bytes_per_item, pmc, pmc_src, lib_sha, extra=None):
+    """All ceilings for one kernel; `bound` = the ceiling it sits closest to."""
+    sec = ms * 1e-3
+    out = {"kernel": name, "launches": int(launches), "avg_launch_ms": round(ms / max(1, launches), 4),
+           item_name + "_per_launch": round(items / max(1, launches), 1),
+           "g%s_per_s" % item_name: round(items / sec / 1e9, 4) if sec > 0 else 0.0}
+    alg = items * alg_bytes_per_item / sec / 1e9 if sec > 0 else 0.0
+    ceilings = {}
+    hbm = {"algorithmic_bytes_per_%s" % item_name[:-1]: round(alg_bytes_per_item, 1), "algorithmic_GBs": round(alg, 1),
+           "algorithmic_frac_of_hbm_peak": round(alg / HBM_PEAK_GBS, 4)}
+    k = (pmc or {}).get("kernels", {}).get(name)
+    traffic = None
+    if k:
+        stale = bool(lib_sha and pmc.get("library_sha16") and pmc["library_sha16"] != lib_sha)
+        src = {"source": pmc_src, "stale": stale}
+        if k.get("hbm_bytes_per_item") is not None:
+            cb = items * k["hbm_bytes_per_item"] / sec / 1e9 if sec > 0 else 0.0
+            traffic = k["hbm_bytes_per_item"] * items / max(1, launches)
+            hbm.update({"counter_bytes_per_%s" % item_name[:-1]: round(k["hbm_bytes_per_item"], 1), "counter_GBs": round(cb, 1),
+                        "counter_frac_of_hbm_peak": round(cb / HBM_PEAK_GBS, 4), "fetch_correction": k.get("fetch_correction"), **src})
+            ceilings["hbm"] = (cb, HBM_PEAK_GBS, "GB/s")
+        if k.get("valu_insts_per_item") is not None:
+            tl = items * k["valu_insts_per_item"] * 64.0 / sec / 1e12 if sec > 0 else 0.0
+            out["valu"] = {"wave_insts_per_%s" % item_name[:-1]: round(k["valu_insts_per_item"], 1), "achieved_Tlaneops": round(tl, 2),
+                           "peak_Tlaneops": VALU_PEAK_TLOPS, "frac": round(tl / VALU_PEAK_TLOPS, 4), **src}
+            ceilings["valu-issue"] = (tl, VALU_PEAK_TLOPS, "Tlane-op/s")
+    # bytes the kernel requests from the cache hierarchy (= the algorithmic bytes) against the aggregate L2 bandwidth
+    ceilings["l2"] = (alg, L2_PEAK_GBS, "GB/s")
+    if "hbm" not in ceilings:
+        ceilings["hbm-algorithmic"] = (alg, HBM_PEAK_GBS, "GB/s")
+    out["hbm"] = hbm
+    # the binding ceiling: highest achieved / peak among the physically meaningful ones (an algorithmic-bytes / HBM-peak ratio
+    # above what the counters show only says the bytes were served by L1 / L2 / Infinity Cache, so it is not a candidate when
+    # counter traffic is known)
+    cand = {b: v for b, v in ceilings.items() if b != "hbm-algorithmic"} or ceilings
+    bound = max(cand, key=lambda b: cand[b][0] / cand[b][1])
+    a, p, u = ceilings[bound]
+    out.update({"bound": bound, "achieved": round(a, 2), "peak": p, "unit": u, "frac": round(a / p, 5), "traffic": traffic})
+    if traffic is not None:
+        out["traffic_source"] = pmc_src
+    if extra:
+        out.update(extra)
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.inproc:
+        sys.exit(self_launch(args))
+
+    import numpy as np  # noqa: F401
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    inproc = args.inproc and args.gpus > 1
+    if inproc and world != 1:
+        raise SystemExit("--inproc drives all devices from one process: do not start it under torch.distributed.run")
+    if not inproc and world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -69,38 +197,26 @@ def main():
     from platinum_amd.sharding import reduce_accumulator, shard_samples
 
     factory, W, H, full_spp, B = scenes.CONFIGS[args.workload]
-    S, K, Wu = args.spp_per_step, args.steps, args.warmup
+    S, K = args.spp_per_step, args.steps
+    Wu = 0 if args.pmc_pass else args.warmup
     scene = factory()
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    ndev = args.gpus if inproc else 1       # devices driven by THIS process
+    n_gpus = args.gpus if inproc else world
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)  # the accumulator lives in a torch tensor so RCCL can reduce it
 
-    r = Renderer(device=local_rank)
-    # samples of this rank: warm-up first (discarded by the restart below), then K*S timed
-    total_spp = K * S
+    r = Renderer(devices=list(range(ndev))) if inproc else Renderer(device=local_rank)
+    # samples of this process: K*S per device, timed; the warm-up renders (and discards) W*S of the same range first
+    total_spp = K * S * ndev
     first, _ = shard_samples(rank, world, total_spp)
+    policy = abi.NONFINITE_ZERO
 
     def start(spp, first_sample):
         # NONFINITE_ZERO: a NaN/inf sample (the reference's BSDF yields ~1 per 5e8 paths) counts as black instead of
         # poisoning its pixel's running mean; the count is reported in extra.nonfinite_samples.
         r.startRender(scene, (W, H), spp, max_bounces=B, first_sample=first_sample, samples_in_flight=S,
-                      external_accumulator=acc.data_ptr(), nonfinite_policy=abi.NONFINITE_ZERO)
-
-    # ---- warm-up: W untimed steps ----
-    if Wu > 0:
-        start(Wu * S, first)
-        for _ in range(Wu):
-            r.render(S)
-        r.wait()
-    # ---- instrumented sample (outside the timed region): BVH nodes / triangles fetched per ray ----
-    start(total_spp, first)
-    r.measureTraversal(first)
-    st0 = r.stats()
-    nodes_c, tris_c = st0.nodes_per_closest_ray, st0.tris_per_closest_ray
-    nodes_s, tris_s = st0.nodes_per_shadow_ray, st0.tris_per_shadow_ray
-    # restart so the instrumented sample is not part of the timed render
-    start(total_spp, first)
-    r.setProfiling(True)
+                      external_accumulator=acc.data_ptr(), nonfinite_policy=policy)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -108,62 +224,81 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(K):
-        r.render(S)
-    r.wait()
-    reduce_accumulator(acc, world, dist)  # the single RCCL sum-reduce of the accumulation buffer (N > 1)
-    sync()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed_pass():
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            r.render(S * ndev)
+        r.wait()                               # (--inproc: includes the library's RCCL all-reduce of the per-device accumulators)
+        reduce_accumulator(acc, world, dist)   # one process per GPU: the single RCCL sum-reduce of the accumulation buffer
+        sync()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
 
+    # ---- warm-up: W untimed steps ----
+    if Wu > 0:
+        start(Wu * S * ndev, first)
+        for _ in range(Wu):
+            r.render(S * ndev)
+        r.wait()
+    # ---- instrumented sample (outside the timed region): BVH nodes / triangles fetched per ray ----
+    nodes_c = tris_c = nodes_s = tris_s = 0.0
+    if not args.pmc_pass:
+        start(total_spp, first)
+        r.measureTraversal(first)
+        st0 = r.stats()
+        nodes_c, tris_c = st0.nodes_per_closest_ray, st0.tris_per_closest_ray
+        nodes_s, tris_s = st0.nodes_per_shadow_ray, st0.tris_per_shadow_ray
+
+    # ---- the timed region: K steps, per-kernel event timing off ----
+    start(total_spp, first)
+    r.setProfiling(False)
+    elapsed = timed_pass()
     st = r.stats()
-    value = W * H * (K * S) * B * world / elapsed / 1e6
+    value = W * H * (K * S) * B * n_gpus / elapsed / 1e6
+    mean_radiance = float(acc[..., :3].mean().item())
 
-    # ---- roofline of the dominant kernel (closest-hit traversal), HBM-bound accounting ----
-    bytes_closest = st.closest_rays * algorithmic_bytes_closest(nodes_c, tris_c)
-    bytes_shadow = st.shadow_rays * algorithmic_bytes_shadow(nodes_s, tris_s)
-    ms_closest, ms_shadow = st.ms_closest, st.ms_shadow
-    achieved = bytes_closest / (ms_closest * 1e-3) / 1e9 if ms_closest > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("closest_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    launches = max(1, st.launches_closest)
-    roofline = {
-        "kernel": "k_trace_closest",
-        "bound": "hbm",
-        "achieved": round(achieved, 2),
-        "peak": HBM_PEAK_GBS,
-        "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5),
-        "traffic": traffic,
-        "bytes_per_ray": round(algorithmic_bytes_closest(nodes_c, tris_c), 1),
-        "nodes_per_ray": round(nodes_c, 2), "tris_per_ray": round(tris_c, 2),
-        "rays_per_launch": st.closest_rays / launches,
-        "avg_launch_ms": ms_closest / launches,
-        "launches": int(st.launches_closest),
-        "grays_per_s": round(st.closest_rays / (ms_closest * 1e-3) / 1e9, 4) if ms_closest > 0 else 0.0,
-        "shadow_kernel": {
-            "achieved": round(bytes_shadow / (ms_shadow * 1e-3) / 1e9, 2) if ms_shadow > 0 else 0.0,
-            "nodes_per_ray": round(nodes_s, 2), "tris_per_ray": round(tris_s, 2),
-            "grays_per_s": round(st.shadow_rays / (ms_shadow * 1e-3) / 1e9, 4) if ms_shadow > 0 else 0.0,
-        },
-    }
+    # ---- kernel pass: the same K steps again with HIP events around every launch (not part of `value`) ----
+    ks, elapsed_k = st, None
+    if not args.pmc_pass and not args.no_kernel_pass:
+        start(total_spp, first)
+        r.setProfiling(True)
+        elapsed_k = timed_pass()
+        ks = r.stats()
+        r.setProfiling(False)
+
+    lib_sha = library_sha16()
+    pmc, pmc_src = load_pmc_profile(args.workload)
+    blocks = {}
+    if ks.ms_closest > 0:
+        blocks["k_trace_closest"] = kernel_block(
+            "k_trace_closest", ks.closest_rays, "rays", ks.ms_closest, ks.launches_closest, algorithmic_bytes_closest(nodes_c, tris_c), pmc, pmc_src,
+            lib_sha, {"nodes_per_ray": round(nodes_c, 2), "tris_per_ray": round(tris_c, 2)})
+        blocks["k_shade"] = kernel_block("k_shade", ks.shaded_hits, "hits", ks.ms_shade, ks.launches_closest, ALGORITHMIC_BYTES_SHADE, pmc, pmc_src, lib_sha)
+        if ks.ms_shadow > 0:
+            blocks["k_trace_shadow"] = kernel_block(
+                "k_trace_shadow", ks.shadow_rays, "rays", ks.ms_shadow, ks.launches_shadow, algorithmic_bytes_shadow(nodes_s, tris_s), pmc, pmc_src,
+                lib_sha, {"nodes_per_ray": round(nodes_s, 2), "tris_per_ray": round(tris_s, 2)})
+        for name in ("k_trace_closest", "k_trace_shadow"):
+            b = blocks.get(name)
+            if b and "counter_frac_of_hbm_peak" in b["hbm"]:
+                b["hbm"]["target_frac"] = HBM_TARGET_FRAC
+                b["hbm"]["target_met"] = bool(b["hbm"]["counter_frac_of_hbm_peak"] >= HBM_TARGET_FRAC)
+    times = {"k_trace_closest": ks.ms_closest, "k_shade": ks.ms_shade, "k_trace_shadow": ks.ms_shadow}
+    dominant = max(times, key=times.get) if blocks else None
+    roofline = dict(blocks[dominant]) if dominant else None
+    if roofline is not None:
+        roofline["share_of_kernel_time"] = round(times[dominant] / max(1e-9, sum(times.values()) + ks.ms_raygen + ks.ms_accumulate), 4)
 
     out = {
         "metric": "Msamples/s (paths x spp x bounces / s) at %dx%d, %d bounces" % (W, H, B),
         "value": round(value, 2),
         "unit": "Msamples/s",
-        "n_gpus": world,
+        "n_gpus": n_gpus,
         "steps": K,
         "warmup": Wu,
         "ms_per_step": round(elapsed / K * 1e3, 3),
@@ -173,47 +308,52 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": {"c1": "C1 Cornell box 512x512", "c2": "C2 Cornell box + GGX dielectric sphere (6144 tris), 1920x1080",
-                         "c3": "C3 1.04M-triangle instanced sphere field, 1920x1080",
-                         "c5": "C5 procedural Sponza-class atrium (258k tris, textures, cut-outs, 4096x2048 environment), 3840x2160"}[args.workload],
-            "width": W, "height": H, "max_bounces": B, "spp_per_step": S, "spp_per_gpu": K * S, "spp_total": K * S * world,
+            "workload": WORKLOADS[args.workload],
+            "width": W, "height": H, "max_bounces": B, "spp_per_step": S, "spp_per_gpu": K * S, "spp_total": K * S * n_gpus,
             "integrator": "MIS+NEE", "flags": "MultiscatterGGX", "triangles": int(st.triangles),
-            "parallelism": "sample-sharded x%d" % world,
+            "nonfinite_policy": "zero (a NaN/inf sample counts as black; parity default is propagate)",
+            "parallelism": ("sample-sharded x%d, one process, library multi-device + RCCL" % n_gpus) if inproc else
+                           ("sample-sharded x%d, one process per GPU + RCCL all-reduce" % n_gpus),
         },
         "roofline": roofline,
+        "roofline_kernels": blocks,
         "extra": {
             "closest_rays": int(st.closest_rays), "shadow_rays": int(st.shadow_rays), "shaded_hits": int(st.shaded_hits),
             "paths": int(st.paths), "nonfinite_samples": int(st.nonfinite_samples), "mean_path_segments": round(st.closest_rays / max(1, st.paths), 3),
             "bvh_build_ms": round(st.bvh_build_ms, 3), "bvh_build_mtris_per_s": round(st.triangles / max(st.bvh_build_ms, 1e-9) / 1e3, 1),
             "bvh_nodes": int(st.bvh_nodes), "bvh_depth4": int(st.bvh_max_depth),
             "upload_ms": round(st.upload_ms, 3),
-            "kernel_ms": {"raygen": round(st.ms_raygen, 2), "closest": round(ms_closest, 2), "shade": round(st.ms_shade, 2),
-                          "shadow": round(ms_shadow, 2), "accumulate": round(st.ms_accumulate, 2)},
+            "kernel_ms": {"raygen": round(ks.ms_raygen, 2), "closest": round(ks.ms_closest, 2), "shade": round(ks.ms_shade, 2),
+                          "shadow": round(ks.ms_shadow, 2), "accumulate": round(ks.ms_accumulate, 2),
+                          "note": "separate pass of the same %d steps with HIP events around every launch" % K,
+                          "pass_wall_ms": round(elapsed_k * 1e3, 2) if elapsed_k else None},
             "wall_ms": round(elapsed * 1e3, 2),
-            "mean_radiance": float(acc[..., :3].mean().item()),
+            "mean_radiance": mean_radiance,
+            "library_sha16": lib_sha,
         },
     }
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload (rank 0, N = 1 only) ----
-    if world == 1 and not args.no_cpu_baseline:
+    if n_gpus == 1 and not args.no_cpu_baseline and not args.pmc_pass:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
         from platinum_amd.renderer import make_params
         threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
         o = oracle_lib.OracleScene(scene, make_params(W, H, 64, B), use_bvh=True)
-        # bounded sample: 1 spp to calibrate, then enough further spp for ~12 s of CPU work; only the second run is reported
+        # bounded sample: 1 spp to calibrate, then enough further spp (>= 4) for ~cpu-seconds of CPU work;
+        # only the second run is reported
         tc0 = time.perf_counter()
         cpu_acc = o.render(0, 1, threads=threads)
         t1spp = time.perf_counter() - tc0
-        cpu_spp = int(max(1, min(63, round(12.0 / max(t1spp, 1e-3)))))
+        cpu_spp = int(max(4, min(63, round(args.cpu_seconds / max(t1spp, 1e-3)))))
         tc0 = time.perf_counter()
         cpu_acc = o.render(1, cpu_spp, acc=cpu_acc, acc_n0=1, threads=threads)
         tc = time.perf_counter() - tc0
         cpu_value = W * H * cpu_spp * B / tc / 1e6
         out["cpu_baseline"] = {
             "value": round(cpu_value, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": "%dx%d x %d spp x %d bounces (sample indices 1..) of the same scene, oracle with its own BVH, %.1f s"
-                      % (W, H, cpu_spp, B, tc),
+            "sample": "%dx%d x %d spp x %d bounces (sample indices 1..%d) of the same scene, oracle with its own BVH, %.1f s"
+                      % (W, H, cpu_spp, B, cpu_spp, tc),
             "gpu_over_cpu": round(value / cpu_value, 1),
         }
         del cpu_acc

@@ -221,6 +221,11 @@ class PtamdError(RuntimeError):
     pass
 
 
+def library_path():
+    """The libptamd.so that load_library() binds ($PTAMD_LIB selects a variant build)."""
+    return os.environ.get("PTAMD_LIB", LIB_PATH)
+
+
 def load_library(path=None):
     """Load libptamd.so and bind every declared symbol.  Raises if the library is not built — there is
     deliberately no fallback implementation."""

@@ -1,56 +1,139 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 output (kernel trace + separate --pmc FETCH_SIZE / WRITE_SIZE passes) for one workload into
-profiles/: copies the kernel_stats CSV, and writes per-kernel HBM traffic per launch as the guide prescribes
-(MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B
-for wide coalesced reads => reported raw AND doubled; our traversal reads are 16-B/lane gathers of 64-B nodes, an
-uncalibrated pattern, so the true read traffic lies between the two numbers)."""
-import csv, glob, json, os, shutil, sys
+"""Summarise the rocprofv3 passes of tools/profile_round.sh for one workload into profiles/:
+
+  <tag>_<wl>_kernel_stats.csv   copy of rocprofv3 --kernel-trace --stats of the default bench command
+  <tag>_<wl>_summary.md         per kernel: calls / avg ms (trace pass); FETCH_SIZE, WRITE_SIZE per launch and per work item,
+                                VALU wave-instructions per work item (--pmc passes of `bench.py --pmc-pass`: full-size batches only)
+  r02_pmc_<wl>.json             what bench.py reads: per-work-item HBM bytes and VALU instructions + the library's sha
+
+Units and corrections as MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports
+half of the bytes of wide coalesced streaming reads.  The factor is CALIBRATED here on the two kernels whose byte counts
+are known exactly: k_accumulate reads (S+1) * 16 B and writes 16 B per pixel, k_raygen writes 68 B per path.
+The traversal kernels read 64-B nodes / 48-B triangle records as 16-B-per-lane gathers — a pattern the guide leaves
+uncalibrated — so their read traffic is given raw and corrected (x the calibrated streaming factor = an upper bound)."""
+import csv, glob, hashlib, json, os, shutil, sys
 from collections import defaultdict
 
-prof_dir, wl, tag = sys.argv[1], sys.argv[2], sys.argv[3]  # e.g. gpurun_out/prof c2 r01
-out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+prof_dir, wl, tag = sys.argv[1], sys.argv[2], sys.argv[3]  # e.g. gpurun_out/prof c3 r02
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_dir = os.path.join(root, "profiles")
 os.makedirs(out_dir, exist_ok=True)
 
+KEYS = ("k_trace_closest<false>", "k_trace_closest<true>", "k_trace_shadow<false>", "k_trace_shadow<true>", "k_shade_nee", "k_shade", "k_raygen",
+        "k_accumulate", "k_fold_counters", "k_chunk_tables", "k_refit", "k_karras", "k_emit", "k_morton", "k_flatten", "k_bounds", "k_hit_records")
+
+
 def short(name):
-    for k in ("k_trace_closest<false>", "k_trace_closest<true>", "k_trace_shadow<false>", "k_trace_shadow<true>", "k_shade", "k_raygen",
-              "k_accumulate", "k_fold_counters", "k_refit", "k_karras", "k_emit", "k_morton", "k_flatten", "k_bounds", "k_hit_records"):
+    for k in KEYS:
         if k in name:
             return k
-    if "rocprim" in name: return "rocprim_radix_sort"
+    if "rocprim" in name:
+        return "rocprim_radix_sort"
     return name[:40]
 
-stats = max(glob.glob(os.path.join(prof_dir, f"{wl}_trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)  # newest run
-shutil.copy(stats, os.path.join(out_dir, f"{tag}_{wl}_kernel_stats.csv"))
-rows = list(csv.DictReader(open(stats)))
-summary = {}
-for r in rows:
-    k = short(r["Name"])
-    d = summary.setdefault(k, {"calls": 0, "total_ms": 0.0})
-    d["calls"] += int(r["Calls"]); d["total_ms"] += float(r["TotalDurationNs"]) / 1e6
 
-def counter(kind):
-    f = glob.glob(os.path.join(prof_dir, f"{wl}_{kind}", "*", "*_counter_collection.csv"))
-    acc = defaultdict(lambda: [0, 0.0])
-    if not f: return acc
-    for r in csv.DictReader(open(max(f, key=os.path.getmtime))):
-        k = short(r["Kernel_Name"])
-        acc[k][0] += 1; acc[k][1] += float(r["Counter_Value"])
-    return acc
-fetch, write = counter("fetch"), counter("write")
-lines = [f"# rocprofv3 summary — bench.py --workload {wl} (default: 4 steps x 64 spp, warm-up 2) (MI355X, {tag})", "",
-         "| kernel | calls | total ms | avg ms | FETCH_SIZE KiB/launch (raw) | x2 (gfx950 corr.) | WRITE_SIZE KiB/launch |", "|---|---|---|---|---|---|---|"]
-traffic = {}
-for k, d in sorted(summary.items(), key=lambda kv: -kv[1]["total_ms"]):
-    fl = fetch[k][1] / fetch[k][0] if fetch[k][0] else float("nan")
-    wr = write[k][1] / write[k][0] if write[k][0] else float("nan")
-    lines.append(f"| {k} | {d['calls']} | {d['total_ms']:.3f} | {d['total_ms']/d['calls']:.4f} | {fl:.1f} | {2*fl:.1f} | {wr:.1f} |")
-    traffic[k] = {"fetch_kib_raw": fl, "write_kib": wr, "avg_ms": d["total_ms"] / d["calls"]}
+def newest(pattern):
+    f = glob.glob(pattern, recursive=True)
+    return max(f, key=os.path.getmtime) if f else None
+
+
+stats = newest(os.path.join(prof_dir, f"{wl}_trace", "**", "*_kernel_stats.csv"))
+summary = {}
+if stats:
+    shutil.copy(stats, os.path.join(out_dir, f"{tag}_{wl}_kernel_stats.csv"))
+    for r in csv.DictReader(open(stats)):
+        d = summary.setdefault(short(r["Name"]), {"calls": 0, "total_ms": 0.0})
+        d["calls"] += int(r["Calls"]); d["total_ms"] += float(r["TotalDurationNs"]) / 1e6
+
+
+def counters(kind):
+    """{kernel: {counter: [dispatches, sum]}} of one --pmc pass, and that pass's bench JSON (item counts)."""
+    f = newest(os.path.join(prof_dir, f"{wl}_{kind}", "**", "*_counter_collection.csv"))
+    acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    if f:
+        for r in csv.DictReader(open(f)):
+            a = acc[short(r["Kernel_Name"])][r["Counter_Name"]]
+            a[0] += 1; a[1] += float(r["Counter_Value"])
+    try:
+        j = json.loads([l for l in open(os.path.join(prof_dir, f"{wl}_{kind}.json")) if l.startswith("{")][-1])
+    except Exception:
+        j = None
+    return acc, j
+
+
+fetch, jf = counters("fetch")
+write, jw = counters("write")
+sq, js = counters("sq")
+
+
+def items(j):
+    """work items of a --pmc-pass run, per kernel"""
+    if not j:
+        return {}
+    e, c = j["extra"], j["config"]
+    npix, spp = c["width"] * c["height"], c["spp_per_gpu"]
+    return {"k_trace_closest<false>": e["closest_rays"], "k_trace_shadow<false>": e["shadow_rays"], "k_shade": e["shaded_hits"],
+            "k_shade_nee": e["shaded_hits"], "k_raygen": e["paths"], "k_accumulate": npix * spp, "_npix": npix, "_spp_per_step": c["spp_per_step"],
+            "_steps": j["steps"]}
+
+
+itf, itw, its = items(jf), items(jw), items(js)
+
+# ---- calibration on known byte counts ----
+calib = {}
+if "k_accumulate" in fetch and itf:
+    S = itf["_spp_per_step"]
+    expect = itf["_npix"] * (S + 1) * 16.0 * itf["_steps"]
+    raw = fetch["k_accumulate"]["FETCH_SIZE"][1] * 1024.0
+    calib["fetch_streaming_factor"] = expect / raw if raw else None
+    calib["k_accumulate_read_bytes_expected"] = expect
+    calib["k_accumulate_FETCH_SIZE_bytes_raw"] = raw
+if "k_accumulate" in write and itw:
+    expect = itw["_npix"] * 16.0 * itw["_steps"]
+    raw = write["k_accumulate"]["WRITE_SIZE"][1] * 1024.0
+    calib["write_factor_k_accumulate"] = expect / raw if raw else None
+if "k_raygen" in write and itw:
+    expect = itw["k_raygen"] * 68.0   # rayO 16 + rayD 16 + att 16 + pid 4 + Lbuf 16 per path (kernels.hip k_raygen)
+    raw = write["k_raygen"]["WRITE_SIZE"][1] * 1024.0
+    calib["write_factor_k_raygen"] = expect / raw if raw else None
+    calib["k_raygen_write_bytes_expected"] = expect
+    calib["k_raygen_WRITE_SIZE_bytes_raw"] = raw
+ff = calib.get("fetch_streaming_factor") or 2.0
+
+lines = [f"# rocprofv3 summary — bench.py --workload {wl} (MI355X, {tag})", "",
+         "Durations: `rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --no-cpu-baseline` (both of bench.py's passes)." % wl,
+         "Counters: separate `--pmc` passes of `bench.py --workload %s --pmc-pass --steps 2` (full 64-spp batches only)." % wl, "",
+         "Calibration on known byte counts: " + json.dumps({k: (round(v, 4) if isinstance(v, float) and v < 100 else v) for k, v in calib.items()}), "",
+         "| kernel | calls | total ms | avg ms | FETCH raw MiB/launch | FETCH x%.2f MiB/launch | WRITE MiB/launch | HBM B/item (corr.) | VALU wave-insts/item | items |" % ff,
+         "|---|---|---|---|---|---|---|---|---|---|"]
+pmc = {"source": f"rocprofv3 --pmc passes of `bench.py --workload {wl} --pmc-pass --steps 2` ({tag}); tools/summarize_prof.py",
+       "calibration": calib, "kernels": {}}
+lib = os.environ.get("PTAMD_LIB", os.path.join(root, "platinum_amd", "csrc", "libptamd.so"))
+if os.path.exists(lib):
+    pmc["library_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+names = sorted(set(summary) | set(fetch) | set(write) | set(sq), key=lambda k: -summary.get(k, {"total_ms": 0})["total_ms"])
+for k in names:
+    d = summary.get(k, {"calls": 0, "total_ms": 0.0})
+    fn, fv = fetch[k]["FETCH_SIZE"] if k in fetch else (0, 0.0)
+    wn, wv = write[k]["WRITE_SIZE"] if k in write else (0, 0.0)
+    vn, vv = sq[k]["SQ_INSTS_VALU"] if k in sq else (0, 0.0)
+    fl = fv / fn / 1024.0 if fn else float("nan")
+    wr = wv / wn / 1024.0 if wn else float("nan")
+    ni_f, ni_w, ni_s = itf.get(k), itw.get(k), its.get(k)
+    per_item = (ff * fv * 1024.0 / ni_f + wv * 1024.0 / ni_w) if (ni_f and ni_w and fn and wn) else None
+    valu = vv / ni_s if (ni_s and vn) else None
+    avg = d["total_ms"] / d["calls"] if d["calls"] else float("nan")
+    lines.append(f"| {k} | {d['calls']} | {d['total_ms']:.3f} | {avg:.4f} | {fl:.1f} | {ff*fl:.1f} | {wr:.1f} | "
+                 f"{'%.1f' % per_item if per_item is not None else '-'} | {'%.1f' % valu if valu is not None else '-'} | {ni_s or ni_f or '-'} |")
+    if per_item is not None or valu is not None:
+        e = {"hbm_bytes_per_item": per_item, "fetch_bytes_raw_per_item": fv * 1024.0 / ni_f if (ni_f and fn) else None,
+             "write_bytes_per_item": wv * 1024.0 / ni_w if (ni_w and wn) else None, "fetch_correction": ff, "valu_insts_per_item": valu}
+        if k in sq:
+            for c in ("SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY"):
+                if c in sq[k] and ni_s:
+                    e[c.lower() + "_per_item"] = sq[k][c][1] / ni_s
+        pmc["kernels"][k.replace("<false>", "")] = e
 open(os.path.join(out_dir, f"{tag}_{wl}_summary.md"), "w").write("\n".join(lines) + "\n")
-c = traffic.get("k_trace_closest<false>")
-if c:
-    json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --workload {wl} (1 step x 64 spp), {tag}",
-               "closest_hbm_bytes_per_launch": (2 * c["fetch_kib_raw"] + c["write_kib"]) * 1024,
-               "closest_fetch_bytes_raw": c["fetch_kib_raw"] * 1024, "closest_write_bytes": c["write_kib"] * 1024,
-               "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (upper bound for this gather pattern)"},
-              open(os.path.join(out_dir, f"traffic_{wl}.json"), "w"), indent=1)
+if pmc["kernels"]:
+    json.dump(pmc, open(os.path.join(out_dir, f"r02_pmc_{wl}.json"), "w"), indent=1)
 print("\n".join(lines))
