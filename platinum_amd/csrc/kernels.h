@@ -9,19 +9,22 @@ namespace pt {
 
 constexpr int kBlock = 256;  // 4 waves; traversal kernels keep a 16 KiB LDS stack slab per block
 
-struct WaveStats { unsigned long long closest, shadow, shaded, paths; };  // per-wave, owner-updated, reduced by k_fold_counters
+struct WaveStats { unsigned long long closest, shadow, shaded, paths; };  // per physical wave, owner-updated, reduced by k_fold_counters
 
-// Wave-private queue segments (kernels.hip): wave w owns slots [w*seg_cap, (w+1)*seg_cap) of every queue array.
+// Queue segments (kernels.hip): segment s = the queue share of tiles [s * tiles_per_seg, (s + 1) * tiles_per_seg) under all
+// samples of a batch; it owns `seg_cap` slots of every queue array (chunk-interleaved) and one count per queue.
 struct Segments {
-  uint32_t* active[2];  // [state buffer][wave] live paths in the wave's segment
-  uint32_t* shadow;     // [wave] shadow rays in the wave's segment
-  WaveStats* stats;     // [wave]
-  uint32_t* table_closest;  // dense lists of non-empty chunks, (k << 16) | wave, rebuilt by k_chunk_tables
+  uint32_t* active[2];  // [state buffer][segment] live paths in the segment
+  uint32_t* shadow;     // [segment] shadow rays in the segment
+  WaveStats* stats;     // [nstats] per physical wave of the producer kernels
+  uint32_t* table_closest;  // dense lists of non-empty chunks, (k << 16) | segment, rebuilt by k_chunk_tables
   uint32_t* table_shadow;
-  uint32_t seg_cap;     // slots per wave (a multiple of 64)
-  uint32_t nwaves;      // grid * kBlock / 64 — identical for every kernel of a batch
+  uint32_t seg_cap;     // slots per segment (a multiple of 64) = tiles_per_seg * samples_in_flight * 64
+  uint32_t nseg;        // segments (<= 32768: k_chunk_tables packs the id into 16 bits and scans <= 1024 per block)
+  uint32_t tiles_per_seg;
+  uint32_t bands;         // consecutive segments cycle over this many horizontal bands of the image (nseg % bands == 0)
+  uint32_t nstats;      // WaveStats slots (>= waves of the largest producer grid)
   uint32_t refill_threshold; // trace kernels: refill a wave's idle lanes when fewer than this many still hold a ray (0 = only when all idle)
-  uint32_t tile_contiguous;  // raygen: 1 = a wave owns adjacent tiles, 0 = tiles strided by nwaves (default)
 };
 
 void launch_raygen(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, vec4* Lbuf, Segments seg, BatchCounters* ctr,
@@ -32,6 +35,9 @@ void launch_chunk_tables(hipStream_t s, Segments seg, uint32_t cur, BatchCounter
                          uint32_t bounce_shadow, bool do_shadow);
 void launch_trace_closest(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, vec4* hit, Segments seg, uint32_t cur,
                           BatchCounters* ctr, uint32_t bounce, uint32_t* spill, int32_t* hitlog, uint32_t log_stride, bool count);
+// `grid` blocks of shade_block_threads() threads (a persistent grid: shade_blocks_per_cu() per CU keeps it resident)
+uint32_t shade_block_threads();
+uint32_t shade_blocks_per_cu();
 void launch_shade(hipStream_t s, uint32_t grid, const DeviceScene* S_device, PathState sin, PathState sout, const vec4* hit,
                   ShadowQueue sq, vec4* Lbuf, Segments seg, uint32_t cur, BatchCounters* ctr, uint32_t bounce);
 void launch_trace_shadow(hipStream_t s, uint32_t grid, const DeviceScene& S, ShadowQueue sq, vec4* Lbuf, Segments seg,

@@ -4,20 +4,22 @@
 //     k_trace_closest(b)  ->  k_shade(b)  ->  k_trace_shadow(b)
 // preceded by k_raygen and followed by k_accumulate.  All kernels are stream-ordered; queue sizes never visit the host.
 //
-// Queues are WAVE-PRIVATE SEGMENTS.  Every kernel runs the same grid (Segments::nwaves waves); wave w owns the slots
-// {seg_slot(w, r) : r < seg_cap} of every queue array (chunk-interleaved, see seg_slot) and a count per queue.  Raygen deals 8x8 pixel tiles to the waves
-// round-robin; k_shade shades a wave's own segment and compacts the survivors (ballot + mbcnt prefix) into its own
-// segment of the other state buffer, and its NEE rays into its own shadow segment.  Survivors <= inputs, so a segment
-// never overflows and NO atomic sits on the producer side.  (Round-1 measurement: with one global append counter per
-// queue, raygen and shade were pinned at the ~88 returning atomics/us one L2 address sustains — MI355X_MICROARCH.md
-// "dequeue"; raygen got 6.7x faster without it.)
+// Queues are SEGMENTS.  A segment is the queue share of a few 8x8 pixel tiles (Segments::tiles_per_seg, 1 unless the image
+// has more than 32768 tiles) under all samples of the batch: segment s owns the slots {seg_slot(s, r) : r < seg_cap} of
+// every queue array (chunk-interleaved, see seg_slot) and one count per queue.  A segment is always processed by ONE wave
+// at a time, front to back: k_raygen fills it, k_shade shades it and compacts the survivors (ballot + mbcnt prefix) into
+// the same segment of the other state buffer and its NEE rays into the same segment of the shadow queue.  Survivors <=
+// inputs, so a segment never overflows and NO atomic sits on the producer side.  (Round-1 measurement: with one global
+// append counter per queue, raygen and shade were pinned at the ~88 returning atomics/us one L2 address sustains —
+// MI355X_MICROARCH.md "dequeue"; raygen got 6.7x faster without it.)  The producers are persistent grids whose waves take
+// segments round-robin (wave w: segments w, w + P, w + 2P ...): there are 4-8x more segments than resident waves, so the
+// grid can be sized for whatever occupancy a kernel's registers allow and the tile count never has to divide it.
 // The trace kernels consume DENSE CHUNK TABLES: after every producer, k_chunk_tables lists the non-empty 64-entry
-// chunks of all segments, wave-major (wave 0's chunks, wave 1's, ...), and the trace waves claim runs of that list
-// from one cursor (kClaim chunks per atomic).  A wave owns a few ADJACENT 8x8 pixel tiles under all samples of the
-// batch, so the rays in flight at any moment come from a small neighbourhood of the image — the BVH subtrees they
-// touch stay in L2 — there are no empty chunks to sweep, and a chunk of survivors still comes from one or two tiles.
-// Results are written in place (hit[i], Lbuf[pid]), so it does not matter which wave traces a ray.
-// Statistics are kept per wave (no atomics) and reduced by k_fold_counters.
+// chunks of all segments, segment-major (= image tiles in raster order, each under its samples), and the trace waves
+// claim runs of that list from one cursor (kClaim chunks per atomic): the rays in flight at any moment come from a
+// small neighbourhood of the image — the BVH subtrees they touch stay in L2 — there are no empty chunks to sweep, and
+// a chunk of survivors still comes from one tile.  Results are written in place (hit[i], Lbuf[pid]), so it does not
+// matter which wave traces a ray.  Statistics are kept per physical wave (no atomics) and reduced by k_fold_counters.
 //
 // Compiled with -ffp-contract=off (deterministic fp32 contract, pt_math.h).
 #include <hip/hip_runtime.h>
@@ -37,25 +39,26 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
-__device__ __forceinline__ uint32_t wave_index() { return blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); }
-// Slot of entry r of wave w's segment.  Segments are CHUNK-INTERLEAVED: the k-th 64-entry chunk of every wave is stored
-// back to back ((k * nwaves + w) * 64), so the trace kernels, which walk the chunks in exactly that order, stream
-// through contiguous memory like a dense queue (a wave-major layout cost the closest-hit kernel 1.4x: every chunk
-// then starts a new 44 KB-strided region).
-__device__ __forceinline__ uint32_t seg_slot(uint32_t nwaves, uint32_t w, uint32_t r) { return ((r >> 6) * nwaves + w) * 64u + (r & 63u); }
+// physical wave id / count of the launch (blockDim.x is a multiple of 64)
+__device__ __forceinline__ uint32_t wave_index() { return blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); }
+__device__ __forceinline__ uint32_t wave_count() { return gridDim.x * (blockDim.x >> 6); }
+// Slot of entry r of segment s.  Segments are CHUNK-INTERLEAVED: the k-th 64-entry chunk of every segment is stored
+// back to back ((k * nseg + s) * 64): chunk k of neighbouring tiles is contiguous, and no segment's base address
+// aliases another's in the memory channels (a segment-major layout cost the closest-hit kernel 1.4x).
+__device__ __forceinline__ uint32_t seg_slot(uint32_t nseg, uint32_t s, uint32_t r) { return ((r >> 6) * nseg + s) * 64u + (r & 63u); }
 
 // ---- chunk claims for the trace kernels ------------------------------------------------------------------------------
 constexpr uint32_t kClaim = 2;  // 64-ray chunks claimed per cursor atomic
 
 struct ChunkClaims {
-  const uint32_t* __restrict__ table;   // [total] (k << 16) | w  for every non-empty chunk, wave-major
-  const uint32_t* __restrict__ counts;  // [nwaves] rays per segment
+  const uint32_t* __restrict__ table;   // [total] (k << 16) | s  for every non-empty chunk, segment-major
+  const uint32_t* __restrict__ counts;  // [nseg] rays per segment
   uint32_t* cursor;
-  uint32_t nwaves, total, lane;
+  uint32_t nseg, total, lane;
   uint32_t next_c, end_c;
   __device__ __forceinline__ void init(const uint32_t* tab, uint32_t total_, const uint32_t* c, uint32_t* cur, const Segments& seg,
                                        uint32_t lane_) {
-    table = tab; total = total_; counts = c; cursor = cur; nwaves = seg.nwaves; lane = lane_;
+    table = tab; total = total_; counts = c; cursor = cur; nseg = seg.nseg; lane = lane_;
     next_c = end_c = 0;
   }
   // ---- per-lane ray replacement ----
@@ -80,10 +83,10 @@ struct ChunkClaims {
           end_c = base + kClaim < total ? base + kClaim : total;
         }
         const uint32_t e = table[next_c++];
-        const uint32_t wv = e & 0xffffu, k = e >> 16;
-        const uint32_t n = counts[wv];
+        const uint32_t sg = e & 0xffffu, k = e >> 16;
+        const uint32_t n = counts[sg];
         const uint32_t left = n - k * 64u;  // > 0: the table lists non-empty chunks only
-        pool_next = seg_slot(nwaves, wv, k * 64u);
+        pool_next = seg_slot(nseg, sg, k * 64u);
         pool_end = pool_next + (left < 64u ? left : 64u);
       }
       if (need && got == kInvalidRef) {
@@ -94,30 +97,12 @@ struct ChunkClaims {
       pool_next += want < avail ? want : avail;
     }
   }
-
-  // Wave-uniform. Returns this lane's queue index, kInvalidRef for an idle lane; `done` when the list is exhausted.
-  __device__ __forceinline__ uint32_t next(bool& done) {
-    done = false;
-    if (next_c == end_c) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(cursor, kClaim);
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (base >= total) { done = true; return kInvalidRef; }
-      next_c = base;
-      end_c = base + kClaim < total ? base + kClaim : total;
-    }
-    const uint32_t e = table[next_c++];
-    const uint32_t wv = e & 0xffffu, k = e >> 16;
-    const uint32_t n = counts[wv];
-    const uint32_t r = k * 64u + lane;
-    return r < n ? seg_slot(nwaves, wv, r) : kInvalidRef;
-  }
 };
 
-// Lists the non-empty chunks of every segment, wave-major.  blockIdx.y = 0: the closest-hit queue (state buffer `cur`);
-// 1: the shadow queue.  kTableBlocks blocks per list, each owning a contiguous slice of the producer waves: a block first sums
-// the chunk counts of all waves before its slice (its base offset), scans its own slice in LDS, then all of its threads write
-// the slice's entries cooperatively (entry -> wave by binary search in the LDS prefix), so the stores are coalesced.  (One block
+// Lists the non-empty chunks of every segment, segment-major.  blockIdx.y = 0: the closest-hit queue (state buffer `cur`);
+// 1: the shadow queue.  kTableBlocks blocks per list, each owning a contiguous slice of the segments: a block first sums
+// the chunk counts of all segments before its slice (its base offset), scans its own slice in LDS, then all of its threads write
+// the slice's entries cooperatively (entry -> segment by binary search in the LDS prefix), so the stores are coalesced.  (One block
 // per list took 0.18 ms per call at 64 samples in flight — 2.5 % of a C2 step.)
 constexpr uint32_t kTableBlocks = 32;
 __global__ void __launch_bounds__(1024) k_chunk_tables(Segments seg, uint32_t cur, BatchCounters* __restrict__ ctr,
@@ -128,12 +113,12 @@ __global__ void __launch_bounds__(1024) k_chunk_tables(Segments seg, uint32_t cu
   uint32_t* __restrict__ table = sh ? seg.table_shadow : seg.table_closest;
   __shared__ uint32_t part[1024];
   __shared__ uint32_t base_sh;
-  const uint32_t slice = (seg.nwaves + kTableBlocks - 1) / kTableBlocks;  // waves per block (<= 1024 for nwaves <= 32768)
+  const uint32_t slice = (seg.nseg + kTableBlocks - 1) / kTableBlocks;  // segments per block (<= 1024 for nseg <= 32768)
   const uint32_t w_begin = blockIdx.x * slice;
-  const uint32_t w_end = w_begin + slice < seg.nwaves ? w_begin + slice : seg.nwaves;
-  // base = chunks of all waves before this slice; the last block also learns the grand total
+  const uint32_t w_end = w_begin + slice < seg.nseg ? w_begin + slice : seg.nseg;
+  // base = chunks of all segments before this slice; the last block also learns the grand total
   uint32_t before = 0, total = 0;
-  for (uint32_t w = threadIdx.x; w < seg.nwaves; w += 1024) {
+  for (uint32_t w = threadIdx.x; w < seg.nseg; w += 1024) {
     const uint32_t nc = (counts[w] + 63u) / 64u;
     total += nc;
     if (w < w_begin) before += nc;
@@ -153,7 +138,7 @@ __global__ void __launch_bounds__(1024) k_chunk_tables(Segments seg, uint32_t cu
     }
     __syncthreads();
   }
-  // inclusive scan of this slice's per-wave chunk counts (thread t <-> wave w_begin + t)
+  // inclusive scan of this slice's per-segment chunk counts (thread t <-> segment w_begin + t)
   const uint32_t mine = (w_begin + threadIdx.x < w_end) ? (counts[w_begin + threadIdx.x] + 63u) / 64u : 0u;
   part[threadIdx.x] = mine;
   __syncthreads();
@@ -176,46 +161,49 @@ __global__ void __launch_bounds__(1024) k_chunk_tables(Segments seg, uint32_t cu
 
 // ---- raygen ------------------------------------------------------------------------------------------------------
 // One 8x8 pixel tile of one sample per wave iteration (a coherent camera-ray bundle).  Lanes outside the image
-// (partial edge tiles) are squeezed out.
+// (partial edge tiles) are squeezed out.  Segment s = T consecutive tiles under all samples of the batch
+// (tile-major, sample-minor): consecutive chunks are the same 8x8 pixels under successive samples.
 __global__ void __launch_bounds__(kBlock) k_raygen(DeviceScene S, PathState st, vec4* __restrict__ Lbuf, Segments seg,
                                                     BatchCounters* __restrict__ ctr, uint32_t first_sample,
                                                     uint32_t nsamples, uint32_t tilesX, uint32_t tilesY) {
   const uint32_t lane = wave_lane();
-  const uint32_t w = wave_index();
   const uint32_t tiles = tilesX * tilesY;
-  // Wave w owns tiles w, w + nwaves, w + 2 nwaves, ... under all samples of the batch (tile-major, sample-minor): its
-  // consecutive chunks are the same 8x8 pixels under successive samples, so a chunk of survivors still comes from one
-  // or two image tiles, and because the tiles of one wave are spread over the image every wave carries a statistically
-  // similar load through k_shade (which is static per wave).
-  const uint32_t per_wave = (tiles + seg.nwaves - 1) / seg.nwaves;
-  uint32_t n_out = 0;
-  for (uint32_t k = 0; k < per_wave * nsamples; k++) {
-    const uint32_t tile = seg.tile_contiguous ? w * per_wave + k / nsamples : (k / nsamples) * seg.nwaves + w;
-    const uint32_t s = k % nsamples;
-    if (tile >= tiles) break;  // wave-uniform
-    const uint32_t ty = tile / tilesX;
-    const uint32_t x = (tile - ty * tilesX) * 8 + (lane & 7);
-    const uint32_t y = ty * 8 + (lane >> 3);
-    const bool valid = x < S.width && y < S.height;
-    RayGenOut rg;
-    if (valid) rg = stage_raygen(S, x, y, first_sample + s);
-    const unsigned long long m = __ballot(valid);
-    if (valid) {
-      const uint32_t j = seg_slot(seg.nwaves, w, n_out + wave_prefix(m));
-      const uint32_t pid = s * (S.width * S.height) + y * S.width + x;
-      st.rayO[j] = vec4{rg.o.x, rg.o.y, rg.o.z, 0.0f};
-      st.rayD[j] = vec4{rg.d.x, rg.d.y, rg.d.z, u2f(rg.dim & kMetaDimMask)};
-      st.att[j] = vec4{1.0f, 1.0f, 1.0f, u2f(rg.offset)};
-      st.pid[j] = pid;
-      Lbuf[pid] = vec4{0.0f, 0.0f, 0.0f, 1.0f};
+  uint32_t started = 0;
+  for (uint32_t sg = wave_index(); sg < seg.nseg; sg += wave_count()) {
+    uint32_t n_out = 0;
+    // segment -> tiles: consecutive segments cycle over `bands` horizontal bands of the image (the chunk tables list the
+    // segments in order, so the rays in flight in a trace kernel come from `bands` neighbourhoods instead of one)
+    const uint32_t per_band = seg.nseg / seg.bands;  // nseg is a multiple of bands
+    const uint32_t first_tile = ((sg % seg.bands) * per_band + sg / seg.bands) * seg.tiles_per_seg;
+    for (uint32_t k = 0; k < seg.tiles_per_seg * nsamples; k++) {
+      const uint32_t tile = first_tile + k / nsamples;
+      const uint32_t s = k % nsamples;
+      if (tile >= tiles) break;  // wave-uniform
+      const uint32_t ty = tile / tilesX;
+      const uint32_t x = (tile - ty * tilesX) * 8 + (lane & 7);
+      const uint32_t y = ty * 8 + (lane >> 3);
+      const bool valid = x < S.width && y < S.height;
+      RayGenOut rg;
+      if (valid) rg = stage_raygen(S, x, y, first_sample + s);
+      const unsigned long long m = __ballot(valid);
+      if (valid) {
+        const uint32_t j = seg_slot(seg.nseg, sg, n_out + wave_prefix(m));
+        const uint32_t pid = s * (S.width * S.height) + y * S.width + x;
+        st.rayO[j] = vec4{rg.o.x, rg.o.y, rg.o.z, 0.0f};
+        st.rayD[j] = vec4{rg.d.x, rg.d.y, rg.d.z, u2f(rg.dim & kMetaDimMask)};
+        st.att[j] = vec4{1.0f, 1.0f, 1.0f, u2f(rg.offset)};
+        st.pid[j] = pid;
+        Lbuf[pid] = vec4{0.0f, 0.0f, 0.0f, 1.0f};
+      }
+      n_out += (uint32_t)__popcll(m);
     }
-    n_out += (uint32_t)__popcll(m);
+    if (lane == 0) seg.active[0][sg] = n_out;
+    started += n_out;
   }
   if (lane == 0) {
-    seg.active[0][w] = n_out;
-    WaveStats& ws = seg.stats[w];
-    ws.paths += n_out;
-    ws.closest += n_out;
+    WaveStats& ws = seg.stats[wave_index()];
+    ws.paths += started;
+    ws.closest += started;
   }
 }
 
@@ -283,7 +271,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_WAVES) k_trace_closest(Device
       const vec4 o4 = st.rayO[ray];
       const vec4 d4 = st.rayD[ray];
       float ir = 0.0f;  // alpha-test payload: the sample drawn before `intersect` (kernel.metal:510), only needed with cut-outs
-      if (S.has_alpha) ir = Halton{S.halton, f2u(st.att[ray].w), f2u(d4.w) & kMetaDimMask}.sample1d();
+      if (S.has_alpha) ir = Halton{halton_table(S.halton), f2u(st.att[ray].w), f2u(d4.w) & kMetaDimMask}.sample1d();
       if (trav_init(S, ts, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 1e-3f, kInf, ir, stack, false, COUNT ? &tc : nullptr)) finish();
     }
     if (__ballot(ray != kInvalidRef) == 0) {
@@ -307,103 +295,184 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_WAVES) k_trace_closest(Device
 }
 
 // ---- shade -----------------------------------------------------------------------------------------------------------
+// Persistent grid sized for the kernel's occupancy (launch_shade); wave w shades segments w, w + P, ...
+// Per block, once: the read-mostly tables every hit touches are staged in LDS — the Halton entries of the dimensions
+// this bounce can reach (5 + 7b .. 15 + 12b: raygen consumes 4, every bounce 7 to 12), the area-light table (binary
+// search + one record per NEE sample) and the E_avg / E_ms_avg energy tables (+ the 64 KB E table with PT_SHADE_LDS_E).
+// Per hit: geometry + material + BSDF set-up, then next-event estimation whose shadow record is compacted into the shadow
+// queue right away, then the BSDF sample / throughput / roulette and the compaction of the survivor.  NEE before the
+// sample (each random number is addressed by its dimension, so the order does not matter) means the shadow record is
+// not held in registers across the sampling code.
 #ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 2
+#define PT_SHADE_WAVES 4   // waves per SIMD the kernel is compiled for (128 VGPRs; 14 spill to scratch)
 #endif
-__global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout,
-                                                                   const vec4* __restrict__ hit, ShadowQueue sq,
-                                                                   vec4* __restrict__ Lbuf, Segments seg, uint32_t cur,
-                                                                   BatchCounters* __restrict__ ctr, uint32_t bounce) {
-  const DeviceScene& S = *Sp;  // scene table read through the scalar cache: by value it cost 100 spilled SGPRs here
-  const uint32_t lane = wave_lane();
-  const uint32_t w = wave_index();
-  const uint32_t n = seg.active[cur][w];
-  uint32_t n_out = 0, n_shadow = 0, shaded = 0;
+#ifndef PT_SHADE_BLOCK
+#define PT_SHADE_BLOCK 256
+#endif
+#ifndef PT_SHADE_LDS_E
+#define PT_SHADE_LDS_E 0
+#endif
+constexpr uint32_t kShadeBlock = PT_SHADE_BLOCK;
+constexpr uint32_t kShadeHalton = 128;  // staged Halton window (entries); dimensions beyond it are read from HBM
+constexpr uint32_t kShadeLights = 64;   // staged area lights; a bigger table is read from HBM
+constexpr int kLutE = 128, kLutEavg = 128, kLutEavgMs = 32;  // table shapes (checked by load_luts)
 
-  for (uint32_t k0 = 0; k0 < n; k0 += 64) {  // wave-uniform trip count: every lane reaches the ballots
-    const uint32_t k = k0 + lane;
-    const uint32_t i = seg_slot(seg.nwaves, w, k);
-    bool alive = false, shadow = false;
-    ShadeOut out;
-    uint32_t pid = 0, offset = 0;
-    if (k < n) {
-      const vec4 h4 = hit[i];
-      const uint32_t tri = f2u(h4.w);
-      if (tri == kInvalidRef) {
+__global__ void __launch_bounds__(PT_SHADE_BLOCK, (PT_SHADE_WAVES * 4 * 64) / PT_SHADE_BLOCK)
+k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const vec4* __restrict__ hit, ShadowQueue sq,
+        vec4* __restrict__ Lbuf, Segments seg, uint32_t cur, BatchCounters* __restrict__ ctr, uint32_t bounce) {
+  const DeviceScene& S = *Sp;  // scene table read through the scalar cache: by value it cost 100 spilled SGPRs here
+  __shared__ HaltonEntry lds_halton[kShadeHalton];
+  __shared__ pt_area_light lds_lights[kShadeLights];
+  __shared__ float lds_Eavg[kLutEavg];
+  __shared__ float lds_EavgMs[kLutEavgMs * kLutEavgMs];
+#if PT_SHADE_LDS_E
+  __shared__ float lds_E[kLutE * kLutE];
+#endif
+  const uint32_t halton_base = 5u + 7u * bounce;
+  uint32_t halton_count = 11u + 5u * bounce;
+  if (halton_base >= (uint32_t)kHaltonDims) halton_count = 0;
+  else if (halton_base + halton_count > (uint32_t)kHaltonDims) halton_count = (uint32_t)kHaltonDims - halton_base;
+  if (halton_count > kShadeHalton) halton_count = kShadeHalton;
+  const bool lights_in_lds = S.lightCount <= kShadeLights;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(S.halton + halton_base);
+    uint4* dst = reinterpret_cast<uint4*>(lds_halton);
+    for (uint32_t i = threadIdx.x; i < halton_count * 2; i += kShadeBlock) dst[i] = ldg(&src[i]);
+    if (lights_in_lds) {
+      const uint4* ls = reinterpret_cast<const uint4*>(S.lights);
+      uint4* ld = reinterpret_cast<uint4*>(lds_lights);
+      for (uint32_t i = threadIdx.x; i < S.lightCount * 3; i += kShadeBlock) ld[i] = ldg(&ls[i]);
+    }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kLutEavg; i += kShadeBlock) lds_Eavg[i] = ldg(&S.luts.Eavg.d[i]);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(kLutEavgMs * kLutEavgMs); i += kShadeBlock) lds_EavgMs[i] = ldg(&S.luts.EavgMs.d[i]);
+#if PT_SHADE_LDS_E
+    {
+      const uint4* es = reinterpret_cast<const uint4*>(S.luts.E.d);
+      uint4* ed = reinterpret_cast<uint4*>(lds_E);
+      for (uint32_t i = threadIdx.x; i < (uint32_t)(kLutE * kLutE / 4); i += kShadeBlock) ed[i] = ldg(&es[i]);
+    }
+#endif
+  }
+  __syncthreads();
+  ShadeTables T;
+  T.luts.E = Lut{S.luts.E.d, kLutE, kLutE, 1, 0};
+  T.luts.Eavg = Lut{lds_Eavg, kLutEavg, 1, 1, 1};
+  T.luts.EMs = Lut{S.luts.EMs.d, S.luts.EMs.w, S.luts.EMs.h, S.luts.EMs.depth, 0};
+  T.luts.EavgMs = Lut{lds_EavgMs, kLutEavgMs, kLutEavgMs, 1, 1};
+  T.luts.ETransIn = Lut{S.luts.ETransIn.d, S.luts.ETransIn.w, S.luts.ETransIn.h, S.luts.ETransIn.depth, 0};
+  T.luts.ETransOut = Lut{S.luts.ETransOut.d, S.luts.ETransOut.w, S.luts.ETransOut.h, S.luts.ETransOut.depth, 0};
+#if PT_SHADE_LDS_E
+  T.luts.E = Lut{lds_E, kLutE, kLutE, 1, 1};
+#endif
+  T.halton = HaltonTab{S.halton, lds_halton, halton_base, halton_count};
+  T.lights = lights_in_lds ? lds_lights : S.lights;
+  T.lights_lds = lights_in_lds ? 1 : 0;
+
+  const uint32_t lane = wave_lane();
+  uint32_t shaded = 0, total_out = 0, total_shadow = 0;
+  // first segment = the wave's index; further ones are claimed from a per-launch cursor (segments differ in size by the
+  // time the later bounces are reached, so a static deal would leave waves idle at the end of every launch)
+  uint32_t sg = wave_index();
+  while (sg < seg.nseg) {
+    const uint32_t n = seg.active[cur][sg];
+    uint32_t n_out = 0, n_shadow = 0;
+    for (uint32_t k0 = 0; k0 < n; k0 += 64) {  // wave-uniform trip count
+      const uint32_t k = k0 + lane;
+      const uint32_t i = seg_slot(seg.nseg, sg, k);
+      uint32_t tri = kInvalidRef;
+      vec4 h4{};
+      if (k < n) { h4 = hit[i]; tri = f2u(h4.w); }
+      if (k < n && tri == kInvalidRef && S.env_texture >= 0) {
         // a miss ends the path; it adds the environment's radiance if there is one (kernel.metal:517-539), then
         // attenuation * backgroundColor (= 0, defs.metal:21)
-        if (S.env_texture >= 0) {
-          const vec4 o4 = sin.rayO[i];
-          const vec4 d4 = sin.rayD[i];
-          const vec4 a4 = sin.att[i];
-          const vec3 Le = stage_miss(S, v3(d4.x, d4.y, d4.z), v3(a4.x, a4.y, a4.z), bounce, o4.w, (f2u(d4.w) & kMetaSpecular) != 0);
-          const uint32_t mpid = sin.pid[i];
-          vec4 L = Lbuf[mpid];
-          L.x += Le.x; L.y += Le.y; L.z += Le.z;
-          Lbuf[mpid] = L;
-        }
-      } else {
         const vec4 o4 = sin.rayO[i];
         const vec4 d4 = sin.rayD[i];
         const vec4 a4 = sin.att[i];
-        pid = sin.pid[i];
+        const vec3 Le = stage_miss(S, v3(d4.x, d4.y, d4.z), v3(a4.x, a4.y, a4.z), bounce, o4.w, (f2u(d4.w) & kMetaSpecular) != 0);
+        const uint32_t mpid = sin.pid[i];
+        vec4 L = Lbuf[mpid];
+        L.x += Le.x; L.y += Le.y; L.z += Le.z;
+        Lbuf[mpid] = L;
+      }
+      const bool has = tri != kInvalidRef;
+      uint32_t c_shadow = 0, c_alive = 0;  // written by the lanes inside the divergent region, made wave-uniform after it
+      if (has) {
+        const vec4 o4 = sin.rayO[i];
+        const vec4 d4 = sin.rayD[i];
+        const vec4 a4 = sin.att[i];
+        const uint32_t pid = sin.pid[i];
         const uint32_t meta = f2u(d4.w);
-        offset = f2u(a4.w);
         ShadeIn in;
         in.o = v3(o4.x, o4.y, o4.z);
         in.d = v3(d4.x, d4.y, d4.z);
         in.att = v3(a4.x, a4.y, a4.z);
-        in.lastPdf = o4.w;
+        in.rayO = &sin.rayO[i];
+        in.rayD = &sin.rayD[i];
         in.lastSpecular = (meta & kMetaSpecular) != 0;
-        in.offset = offset;
+        in.offset = f2u(a4.w);
         in.dim = (meta & kMetaDimMask) + 1;  // +1: the alpha-test payload `ir` drawn before intersect (kernel.metal:510)
         in.bounce = bounce;
         in.t = h4.x; in.u = h4.y; in.v = h4.z;
         in.tri = tri;
-        out = stage_shade(S, in);
-        shaded++;
-        alive = out.alive;
-        shadow = out.shadow;
-        if (out.has_emitted) {
+        ShadeGeom g;
+        ShadingContext sc;
+        shade_geometry(S, in, g, sc);
+        const BSDF bsdf(sc, S.flags, T.luts, g.wo);
+        // ---- NEE; its shadow ray goes to this segment of the shadow queue now (ballot over the lanes in here) ----
+        uint32_t dim_rr;
+        {
+          const NeeOut nee = shade_nee(S, T, in, g, sc, bsdf, in.dim + 6);
+          dim_rr = nee.dim;
+          const unsigned long long m = __ballot(nee.shadow);
+          if (nee.shadow) {
+            const uint32_t j = seg_slot(seg.nseg, sg, n_shadow + wave_prefix(m));
+            sq.o[j] = vec4{g.hitPos.x, g.hitPos.y, g.hitPos.z, nee.tmax};
+            sq.d[j] = vec4{nee.d.x, nee.d.y, nee.d.z, u2f(pid)};
+            sq.contrib[j] = vec4{nee.contrib.x, nee.contrib.y, nee.contrib.z, nee.payload};
+          }
+          c_shadow = (uint32_t)__popcll(m);
+        }
+        // ---- BSDF sample, emission, throughput, roulette; survivors -> this segment of the next bounce's queue ----
+        const BounceOut bo = shade_bounce(S, T, in, g, sc, bsdf, dim_rr);
+        if (bo.has_emitted) {
           vec4 L = Lbuf[pid];
-          L.x += out.emitted.x; L.y += out.emitted.y; L.z += out.emitted.z;
+          L.x += bo.emitted.x; L.y += bo.emitted.y; L.z += bo.emitted.z;
           Lbuf[pid] = L;
         }
+        const unsigned long long m = __ballot(bo.alive);
+        if (bo.alive) {
+          const uint32_t j = seg_slot(seg.nseg, sg, n_out + wave_prefix(m));
+          sout.rayO[j] = vec4{g.hitPos.x, g.hitPos.y, g.hitPos.z, bo.next_pdf};
+          sout.rayD[j] = vec4{bo.next_d.x, bo.next_d.y, bo.next_d.z, u2f((bo.dim & kMetaDimMask) | (bo.next_specular ? kMetaSpecular : 0u))};
+          sout.att[j] = vec4{bo.next_att.x, bo.next_att.y, bo.next_att.z, u2f(in.offset)};
+          sout.pid[j] = pid;
+        }
+        c_alive = (uint32_t)__popcll(m);
+      }
+      // the counts of the lanes that were in the region, for every lane (the queue cursors are wave-uniform)
+      const unsigned long long mh = __ballot(has);
+      if (mh) {
+        const int src = __builtin_ctzll(mh);
+        n_shadow += (uint32_t)__builtin_amdgcn_readlane((int)c_shadow, src);
+        n_out += (uint32_t)__builtin_amdgcn_readlane((int)c_alive, src);
+        shaded += (uint32_t)__popcll(mh);
       }
     }
-    // survivors -> this wave's segment of the next bounce's queue
-    {
-      const unsigned long long m = __ballot(alive);
-      if (alive) {
-        const uint32_t j = seg_slot(seg.nwaves, w, n_out + wave_prefix(m));
-        sout.rayO[j] = vec4{out.next_o.x, out.next_o.y, out.next_o.z, out.next_pdf};
-        sout.rayD[j] = vec4{out.next_d.x, out.next_d.y, out.next_d.z,
-                            u2f((out.dim & kMetaDimMask) | (out.next_specular ? kMetaSpecular : 0u))};
-        sout.att[j] = vec4{out.next_att.x, out.next_att.y, out.next_att.z, u2f(offset)};
-        sout.pid[j] = pid;
-      }
-      n_out += (uint32_t)__popcll(m);
+    if (lane == 0) {
+      seg.active[cur ^ 1][sg] = n_out;
+      seg.shadow[sg] = n_shadow;
     }
-    // NEE shadow rays -> this wave's shadow segment
-    {
-      const unsigned long long m = __ballot(shadow);
-      if (shadow) {
-        const uint32_t j = seg_slot(seg.nwaves, w, n_shadow + wave_prefix(m));
-        sq.o[j] = vec4{out.shadow_o.x, out.shadow_o.y, out.shadow_o.z, out.shadow_tmax};
-        sq.d[j] = vec4{out.shadow_d.x, out.shadow_d.y, out.shadow_d.z, u2f(pid)};
-        sq.contrib[j] = vec4{out.shadow_contrib.x, out.shadow_contrib.y, out.shadow_contrib.z, out.shadow_payload};
-      }
-      n_shadow += (uint32_t)__popcll(m);
-    }
+    total_out += n_out;
+    total_shadow += n_shadow;
+    uint32_t next = 0;
+    if (lane == 0) next = wave_count() + atomicAdd(&ctr->work_shade[bounce], 1u);
+    sg = __builtin_amdgcn_readfirstlane(next);
   }
-  const uint32_t ns = wave_sum(shaded);
   if (lane == 0) {
-    seg.active[cur ^ 1][w] = n_out;
-    seg.shadow[w] = n_shadow;
-    WaveStats& ws = seg.stats[w];
-    ws.closest += n_out;
-    ws.shadow += n_shadow;
-    ws.shaded += ns;
+    WaveStats& ws = seg.stats[wave_index()];
+    ws.closest += total_out;
+    ws.shadow += total_shadow;
+    ws.shaded += shaded;
   }
 }
 
@@ -571,7 +640,7 @@ __global__ void __launch_bounds__(kBlock) k_fold_counters(const BatchCounters* _
   // one block: reduce the per-wave statistics, then clear them for the next batch
   __shared__ unsigned long long red[4][kBlock];
   unsigned long long a[4] = {0, 0, 0, 0};
-  for (uint32_t w = threadIdx.x; w < seg.nwaves; w += kBlock) {
+  for (uint32_t w = threadIdx.x; w < seg.nstats; w += kBlock) {
     WaveStats& ws = seg.stats[w];
     a[0] += ws.closest; a[1] += ws.shadow; a[2] += ws.shaded; a[3] += ws.paths;
     ws.closest = 0; ws.shadow = 0; ws.shaded = 0; ws.paths = 0;
@@ -606,21 +675,22 @@ __global__ void __launch_bounds__(kBlock) k_shade_records(DeviceScene S, ShadeRe
 __global__ void __launch_bounds__(kBlock) k_hit_records(DeviceScene S, PathState st, const vec4* __restrict__ hit, Segments seg,
                                                          pt_hit_record* __restrict__ out) {
   const uint32_t lane = wave_lane();
-  const uint32_t w = wave_index();
-  const uint32_t n = seg.active[0][w];
-  for (uint32_t k = lane; k < n; k += 64) {
-    const uint32_t i = seg_slot(seg.nwaves, w, k);
-    const vec4 h = hit[i];
-    const uint32_t tri = f2u(h.w);
-    pt_hit_record r;
-    if (tri != kInvalidRef) {
-      r.t = h.x; r.u = h.y; r.v = h.z;
-      r.instance = (int32_t)S.tris[tri].inst;
-      r.primitive = (int32_t)S.tris[tri].prim;
-    } else {
-      r.t = 0.0f; r.u = 0.0f; r.v = 0.0f; r.instance = -1; r.primitive = -1;
+  for (uint32_t sg = wave_index(); sg < seg.nseg; sg += wave_count()) {
+    const uint32_t n = seg.active[0][sg];
+    for (uint32_t k = lane; k < n; k += 64) {
+      const uint32_t i = seg_slot(seg.nseg, sg, k);
+      const vec4 h = hit[i];
+      const uint32_t tri = f2u(h.w);
+      pt_hit_record r;
+      if (tri != kInvalidRef) {
+        r.t = h.x; r.u = h.y; r.v = h.z;
+        r.instance = (int32_t)S.tris[tri].inst;
+        r.primitive = (int32_t)S.tris[tri].prim;
+      } else {
+        r.t = 0.0f; r.u = 0.0f; r.v = 0.0f; r.instance = -1; r.primitive = -1;
+      }
+      out[st.pid[i]] = r;
     }
-    out[st.pid[i]] = r;
   }
 }
 
@@ -641,9 +711,11 @@ void launch_trace_closest(hipStream_t s, uint32_t grid, const DeviceScene& S, Pa
   else
     hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(kBlock), 0, s, S, st, hit, seg, cur, ctr, bounce, spill, hitlog, log_stride);
 }
+uint32_t shade_block_threads() { return kShadeBlock; }
+uint32_t shade_blocks_per_cu() { return (PT_SHADE_WAVES * 4 * 64) / PT_SHADE_BLOCK; }
 void launch_shade(hipStream_t s, uint32_t grid, const DeviceScene* S, PathState sin, PathState sout, const vec4* hit,
                   ShadowQueue sq, vec4* Lbuf, Segments seg, uint32_t cur, BatchCounters* ctr, uint32_t bounce) {
-  hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, s, S, sin, sout, hit, sq, Lbuf, seg, cur, ctr, bounce);
+  hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kShadeBlock), 0, s, S, sin, sout, hit, sq, Lbuf, seg, cur, ctr, bounce);
 }
 void launch_trace_shadow(hipStream_t s, uint32_t grid, const DeviceScene& S, ShadowQueue sq, vec4* Lbuf, Segments seg,
                          BatchCounters* ctr, uint32_t bounce, uint32_t* spill, bool count) {

@@ -28,26 +28,28 @@ PT_HD LutAxis lut_axis(float c, int n) {
   a.i1 = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
   return a;
 }
+// one texel: from the block's LDS copy when the table was staged there, from HBM (global_load) otherwise
+PT_HD float lut_tap(const Lut& l, int i) { return l.lds ? l.d[i] : ldg(&l.d[i]); }
 PT_HD float lut1(const Lut& l, float cx) {
   LutAxis ax = lut_axis(cx, l.w);
-  float a = l.d[ax.i0], b = l.d[ax.i1];
+  float a = lut_tap(l, ax.i0), b = lut_tap(l, ax.i1);
   return a + (b - a) * ax.w;
 }
-PT_HD float lut2_slice(const float* __restrict__ d, int W, const LutAxis& ax, const LutAxis& ay) {
-  float t00 = d[ay.i0 * W + ax.i0], t01 = d[ay.i0 * W + ax.i1];
-  float t10 = d[ay.i1 * W + ax.i0], t11 = d[ay.i1 * W + ax.i1];
+PT_HD float lut2_slice(const Lut& l, int base, int W, const LutAxis& ax, const LutAxis& ay) {
+  float t00 = lut_tap(l, base + ay.i0 * W + ax.i0), t01 = lut_tap(l, base + ay.i0 * W + ax.i1);
+  float t10 = lut_tap(l, base + ay.i1 * W + ax.i0), t11 = lut_tap(l, base + ay.i1 * W + ax.i1);
   float a = t00 + (t01 - t00) * ax.w;
   float b = t10 + (t11 - t10) * ax.w;
   return a + (b - a) * ay.w;
 }
 PT_HD float lut2(const Lut& l, float cx, float cy) {
   LutAxis ax = lut_axis(cx, l.w), ay = lut_axis(cy, l.h);
-  return lut2_slice(l.d, l.w, ax, ay);
+  return lut2_slice(l, 0, l.w, ax, ay);
 }
 PT_HD float lut3(const Lut& l, float cx, float cy, float cz) {
   LutAxis ax = lut_axis(cx, l.w), ay = lut_axis(cy, l.h), az = lut_axis(cz, l.depth);
-  float a = lut2_slice(l.d + az.i0 * (l.w * l.h), l.w, ax, ay);
-  float b = lut2_slice(l.d + az.i1 * (l.w * l.h), l.w, ax, ay);
+  float a = lut2_slice(l, az.i0 * (l.w * l.h), l.w, ax, ay);
+  float b = lut2_slice(l, az.i1 * (l.w * l.h), l.w, ax, ay);
   return a + (b - a) * az.w;
 }
 
@@ -61,15 +63,15 @@ struct ShadingContext {
 // sampler(address::repeat, filter::linear) on a decoded float4 texture (filtering contract: DESIGN.md §2)
 PT_HD int tex_wrap(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
 PT_HD vec4 tex_sample(const DeviceScene& S, int id, vec2 uv) {
-  const TexInfo t = S.textures[id];
+  const TexInfo t = ldg(&S.textures[id]);
   const float fx = uv.x * (float)t.w - 0.5f, fy = uv.y * (float)t.h - 0.5f;
   const float x0f = floorf(fx), y0f = floorf(fy);
   const float wx = fx - x0f, wy = fy - y0f;
   const int x0 = tex_wrap((int)x0f, (int)t.w), x1 = tex_wrap((int)x0f + 1, (int)t.w);
   const int y0 = tex_wrap((int)y0f, (int)t.h), y1 = tex_wrap((int)y0f + 1, (int)t.h);
   const vec4* __restrict__ px = S.tex_pixels + t.offset;
-  const vec4 p00 = px[(size_t)y0 * t.w + x0], p01 = px[(size_t)y0 * t.w + x1];
-  const vec4 p10 = px[(size_t)y1 * t.w + x0], p11 = px[(size_t)y1 * t.w + x1];
+  const vec4 p00 = ldg(&px[(size_t)y0 * t.w + x0]), p01 = ldg(&px[(size_t)y0 * t.w + x1]);
+  const vec4 p10 = ldg(&px[(size_t)y1 * t.w + x0]), p11 = ldg(&px[(size_t)y1 * t.w + x1]);
   vec4 o;
   { const float a = p00.x + (p01.x - p00.x) * wx, b = p10.x + (p11.x - p10.x) * wx; o.x = a + (b - a) * wy; }
   { const float a = p00.y + (p01.y - p00.y) * wx, b = p10.y + (p11.y - p10.y) * wx; o.y = a + (b - a) * wy; }

@@ -41,9 +41,28 @@ struct alignas(16) TriRec {
 static_assert(sizeof(TriRec) == 48, "TriRec");
 
 // What shading needs to know about a hit triangle, resolved once per render (k_shade_records) and indexed like tris[]:
-// absolute vertex indices and the absolute index of its MaterialGPU.  Without it every shaded hit walks
-// tris -> instances -> meshes -> indices / slots -> vertices / materials: five dependent loads instead of two.
-struct alignas(16) ShadeRec { uint32_t v[3]; uint32_t material; };
+// absolute vertex indices, the absolute index of its MaterialGPU, its instance, and the world-space geometric normal
+// (kernel.metal:150-162: normalize(M * normalize(cross(p1 - p0, p2 - p0))) — the same operations in the same order as the
+// per-hit formulation, evaluated once per flattened triangle).  32 B = one dwordx4 pair.  Without it every shaded hit walks
+// tris -> instances -> meshes -> indices / slots -> vertices / materials (five dependent loads instead of two) and
+// re-reads three positions only to rebuild this normal.
+struct alignas(16) ShadeRec { uint32_t v[3]; uint32_t material; uint32_t inst; float ng[3]; };
+static_assert(sizeof(ShadeRec) == 32, "ShadeRec");
+
+// A read of scene-table memory that is KNOWN to be global (HBM).  k_shade receives the DeviceScene table through a
+// pointer, so the pointers inside it are "flat" to the compiler: plain dereferences become flat_load (aperture check,
+// both wait counters, 64-bit address VGPRs).  Going through address space 1 yields global_load with an SGPR base.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T>
+__device__ __forceinline__ T ldg(const T* p) {
+  T r;
+  __builtin_memcpy(&r, (const __attribute__((address_space(1))) void*)p, sizeof(T));
+  return r;
+}
+#else
+template <class T>
+PT_HD T ldg(const T* p) { return *p; }
+#endif
 
 // 4-wide BVH node with child boxes quantised to 8 bits per coordinate relative to the node's own box, 64 B =
 // 4 x dwordx4 (one half of a 128-B L2 line).  The traversal kernels are bound by vector-L1 lookups,
@@ -69,20 +88,24 @@ constexpr uint32_t kInvalidRef = 0xffffffffu;
 
 // ---- sampler table: one entry per Halton dimension (defs.metal:115-194 holds the 620 primes) ---------------------
 // 32-bit integer multiplies are quarter rate on CDNA, so the radical inverse peels `digits` base-`prime` digits per
-// 64-bit magic division (by chunk = prime^digits < 2^16) and splits the < 2^16 remainder with exact fp32 arithmetic.
+// division by chunk = prime^digits (< 2^16) and splits the < 2^16 remainder with exact fp32 arithmetic.  The division
+// is the round-up multiply-shift of Granlund & Montgomery with a 33-bit multiplier 2^32 + magic, l = ceil(log2 chunk):
+//   t = mulhi(magic, n);  q = (t + ((n - t) >> 1)) >> (l - 1)          exact for every 32-bit n
+// — ONE quarter-rate multiply per chunk (q * chunk is a 24-bit multiply: q < 2^24 because chunk >= 257).
 struct alignas(16) HaltonEntry {
-  uint32_t chunk;               // prime^digits, < 2^16
-  uint32_t magic_hi, magic_lo;  // M = floor((2^64-1)/chunk) + 1 ; q = (M * n) >> 64 is exact for 32-bit n
-  float inv;                    // 1.0f / (float)prime  (the reference's invB, samplers.metal:172)
-  float primef;                 // (float)prime
-  uint32_t digits;              // digits peeled per chunk (1 for primes >= 257)
+  uint32_t chunk;    // prime^digits, 257 <= chunk < 2^16
+  uint32_t magic;    // floor(2^32 * (2^l - chunk) / chunk) + 1
+  uint32_t shift;    // l - 1
+  float inv;         // 1.0f / (float)prime  (the reference's invB, samplers.metal:172)
+  float primef;      // (float)prime
+  uint32_t digits;   // digits peeled per chunk (1 for primes >= 257)
   uint32_t prime;
   uint32_t _pad;
 };
 constexpr int kHaltonDims = 620;
 
 // ---- LUTs (pt_shader_defs.hpp:130-139) -----------------------------------------------------------------------
-struct Lut { const float* d; int w, h, depth; };
+struct Lut { const float* d; int w, h, depth; int lds; };  // lds != 0: `d` points at a copy a block staged in LDS (k_shade)
 struct LutSet { Lut E, Eavg, EMs, EavgMs, ETransIn, ETransOut; };  // the two *avgTrans tables are never sampled
 
 // ---- scene textures: decoded to linear float4 at upload, sampled with repeat + bilinear ---------------
@@ -150,6 +173,7 @@ struct BatchCounters {
   uint32_t chunks_shadow[64];   // non-empty shadow chunks at bounce b
   uint32_t work_closest[64];  // ordered-claim cursors of the trace kernels
   uint32_t work_shadow[64];
+  uint32_t work_shade[64];    // segment-claim cursor of k_shade at bounce b
   uint32_t shaded;        // hits shaded
   uint32_t nonfinite;     // samples with NaN/inf radiance seen by k_accumulate
   uint32_t _pad[2];

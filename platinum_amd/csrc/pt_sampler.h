@@ -3,7 +3,7 @@
 //   HaltonSampler             samplers.metal:154-184 (ctor, sample1d, sample2d, halton)
 //   sampleDisk / Polar / CosineHemisphere / TriUniform   samplers.metal:200-238
 // The radical inverse keeps the reference's float sequence (f *= 1/b; r += f * digit) exactly; only the integer
-// i / b and i % b are strength-reduced: one 64-bit multiply-high per chunk of digits (HaltonEntry) + exact fp32 digit
+// i / b and i % b are strength-reduced: one 32-bit multiply-high per chunk of digits (HaltonEntry) + exact fp32 digit
 // splitting, identical digits for every 32-bit i.
 #pragma once
 #include "pt_device.h"
@@ -23,17 +23,51 @@ PT_HD uint32_t pcg4d_x(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
   return x;
 }
 
+PT_HD uint32_t mulhi_u32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+// a * b for a, b < 2^24 with a product < 2^32 (v_mul_u32_u24: full rate, where v_mul_lo_u32 is quarter rate)
+PT_HD uint32_t mul_u24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(a, b);
+#else
+  return a * b;
+#endif
+}
+
 PT_HD uint32_t halton_offset(uint32_t px, uint32_t py, uint32_t sample) { return pcg4d_x(px, py, sample, px + py); }
 
-PT_HD float halton(const HaltonEntry* __restrict__ tab, uint32_t i, uint32_t d) {
-  const HaltonEntry e = tab[d];
+// The table entry of one prime (host side: renderer.hip builds the 620-entry table once per renderer).
+inline HaltonEntry make_halton_entry(uint32_t prime) {
+  uint32_t digits = 1;
+  uint64_t chunk = prime;
+  while (chunk * prime < 65536ull) { chunk *= prime; digits++; }
+  uint32_t l = 0;
+  while ((1ull << l) < chunk) l++;  // l = ceil(log2 chunk)
+  const uint64_t magic = ((1ull << 32) * ((1ull << l) - chunk)) / chunk + 1;  // < 2^32
+  return {(uint32_t)chunk, (uint32_t)magic, l - 1, 1.0f / (float)prime, (float)prime, digits, prime, 0u};
+}
+
+// Where the per-dimension entries live: the HBM table (all 620 dimensions) or a window [base, base + count) of it that a
+// block staged in LDS (k_shade: the dimensions one bounce can touch); dimensions outside the window fall back to HBM.
+struct HaltonTab {
+  const HaltonEntry* global;
+  const HaltonEntry* lds;  // nullptr: no staged window
+  uint32_t base, count;
+};
+PT_HD HaltonTab halton_table(const HaltonEntry* global) { return {global, nullptr, 0u, 0u}; }
+PT_HD HaltonEntry halton_entry(const HaltonTab& t, uint32_t d) {
+  if (t.lds != nullptr && d - t.base < t.count) return t.lds[d - t.base];
+  return ldg(&t.global[d]);
+}
+
+PT_HD float halton(const HaltonTab& tab, uint32_t i, uint32_t d) {
+  const HaltonEntry e = halton_entry(tab, d);
   float f = 1.0f;
   float r = 0.0f;
   while (i > 0) {
-    // q = i / chunk via (M * i) >> 64, M = magic_hi:magic_lo ; rem = i % chunk holds `digits` base-prime digits
-    const uint64_t t = (uint64_t)e.magic_hi * i + (((uint64_t)e.magic_lo * i) >> 32);
-    const uint32_t q = (uint32_t)(t >> 32);
-    float rem = (float)(i - q * e.chunk);  // < 2^16: exact
+    // q = i / chunk (HaltonEntry); rem = i % chunk holds `digits` base-prime digits
+    const uint32_t t = mulhi_u32(e.magic, i);
+    const uint32_t q = (t + ((i - t) >> 1)) >> e.shift;
+    float rem = (float)(i - mul_u24(q, e.chunk));  // < 2^16: exact
     if (e.digits == 1) {
       f = f * e.inv;
       r = r + f * rem;
@@ -55,7 +89,7 @@ PT_HD float halton(const HaltonEntry* __restrict__ tab, uint32_t i, uint32_t d) 
 
 // A sampler cursor: (offset, dim) live in the path state between kernels.
 struct Halton {
-  const HaltonEntry* tab;
+  HaltonTab tab;
   uint32_t offset;
   uint32_t dim;
   PT_HD float sample1d() { return halton(tab, offset, dim++); }

@@ -119,7 +119,7 @@ struct pt_renderer {
   pt_tonemap_options tonemap{};
   DevBuf<uint32_t> render_target;  // RGBA8 (renderer_pt.cpp:832-835)
   uint32_t trace_grid = 0, trace_blocks_per_cu = PT_TRACE_WAVES;
-  uint32_t nwaves = 0, seg_cap = 0, blocks_per_cu = 6, tile_contiguous = 0, refill_threshold = 48;
+  uint32_t nseg = 0, tiles_per_seg = 1, seg_bands = 4, tiles_per_seg_override = 0, nstats = 0, seg_cap = 0, blocks_per_cu = 6, shade_grid = 0, refill_threshold = 48;
   DevBuf<BatchCounters> ctr;
   DevBuf<Totals> totals;
   vec4* acc = nullptr;
@@ -139,7 +139,7 @@ struct pt_renderer {
 
   PathState path_state(int k) { return PathState{st_rayO[k].p, st_rayD[k].p, st_att[k].p, st_pid[k].p}; }
   ShadowQueue shadow_queue() { return ShadowQueue{sq_o.p, sq_d.p, sq_c.p}; }
-  Segments segments() { return Segments{{seg_active[0].p, seg_active[1].p}, seg_shadow.p, wave_stats.p, chunk_table[0].p, chunk_table[1].p, seg_cap, nwaves, refill_threshold, tile_contiguous}; }
+  Segments segments() { return Segments{{seg_active[0].p, seg_active[1].p}, seg_shadow.p, wave_stats.p, chunk_table[0].p, chunk_table[1].p, seg_cap, nseg, tiles_per_seg, seg_bands, nstats, refill_threshold}; }
 
   void free_scene() {
     positions.release(); vdata.release(); indices.release(); slots.release(); meshes.release(); instances.release();
@@ -201,7 +201,7 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
     }
     {
       ScopedTimer t(r, K_SHADE);
-      launch_shade(s, r->grid, r->scene_d.p, r->path_state(cur), r->path_state(cur ^ 1), r->hit.p, r->shadow_queue(), r->Lbuf.p, seg, (uint32_t)cur, ctr, b);
+      launch_shade(s, r->shade_grid, r->scene_d.p, r->path_state(cur), r->path_state(cur ^ 1), r->hit.p, r->shadow_queue(), r->Lbuf.p, seg, (uint32_t)cur, ctr, b);
       // closest-hit list of bounce b + 1 (written to chunks_closest[b + 1]) and shadow list of bounce b
       launch_chunk_tables(s, seg, (uint32_t)(cur ^ 1), ctr, b + 1, b, mis);
     }
@@ -279,11 +279,7 @@ int build_halton_table(pt_renderer* r) {
     for (uint32_t d = 2; d * d <= c; d++)
       if (c % d == 0) { prime = false; break; }
     if (!prime) continue;
-    uint32_t digits = 1;
-    uint64_t chunk = c;
-    while (chunk * c < 65536ull) { chunk *= c; digits++; }
-    const uint64_t M = ~0ull / chunk + 1;
-    tab.push_back({(uint32_t)chunk, (uint32_t)(M >> 32), (uint32_t)M, 1.0f / (float)c, (float)c, digits, c, 0u});
+    tab.push_back(make_halton_entry(c));
   }
   PT_HIP(r->halton.upload(tab));
   return PT_OK;
@@ -309,7 +305,8 @@ int pt_create(const pt_create_info* info, pt_renderer** out) {
   pt_default_tonemap_options(&r->tonemap);
   r->device = info->device_ordinal;
   if (const char* e = getenv("PTAMD_REFILL")) r->refill_threshold = (uint32_t)atoi(e);
-  if (const char* e = getenv("PTAMD_TILE_CONTIGUOUS")) r->tile_contiguous = (uint32_t)atoi(e);  // tuning knobs
+  if (const char* e = getenv("PTAMD_TILES_PER_SEG")) r->tiles_per_seg_override = (uint32_t)std::max(0, atoi(e));  // tuning knobs
+  if (const char* e = getenv("PTAMD_SEG_BANDS")) r->seg_bands = (uint32_t)std::max(1, std::min(64, atoi(e)));
   if (const char* e = getenv("PTAMD_BLOCKS_PER_CU")) r->blocks_per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));
   if (const char* e = getenv("PTAMD_TRACE_BLOCKS_PER_CU")) r->trace_blocks_per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));
   hipDeviceProp_t prop;
@@ -467,22 +464,23 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
   }
   sif = std::min<uint32_t>(std::min<uint32_t>(sif, p->spp), 256);
   r->samples_in_flight = sif;
-  // wave-private queue segments: every wave of the persistent grid owns ceil(tiles / nwaves) 8x8 tiles worth of slots
-  // The grid must be fully RESIDENT for the trace kernels (a wave that starts late would serialise its whole segment
-  // behind the others): 6 blocks of 256 threads per CU fit their 16 KiB LDS slab, <= 80 VGPRs and ~96 SGPRs.
-  r->grid = (uint32_t)r->num_cu * r->blocks_per_cu;
-  // the trace kernels claim chunks from a table, so their grid is free: as many blocks as their LDS / VGPR budget keeps resident
+  // Queue segments (kernels.hip): one per 8x8 tile (a few tiles each once the image has more than 32768 of them), each with
+  // room for its tiles under all samples in flight.  The producers (raygen, shade) are persistent grids whose waves take
+  // segments round-robin; the trace kernels claim chunks from a table, so every grid is sized for its own kernel's occupancy.
+  r->grid = (uint32_t)r->num_cu * r->blocks_per_cu;                 // raygen, hit records: 256-thread blocks
+  r->shade_grid = (uint32_t)r->num_cu * shade_blocks_per_cu();     // as many blocks as k_shade's registers / LDS keep resident
   r->trace_grid = (uint32_t)r->num_cu * r->trace_blocks_per_cu;
-  r->nwaves = r->grid * (kBlock / 64);
-  // k_chunk_tables packs the wave id into 16 bits ((k << 16) | w) and scans a slice of <= 1024 waves per table block
-  if (r->nwaves > 32768) return fail(PT_ERR_UNSUPPORTED, "persistent grid too large for the chunk tables (num_cu * blocks_per_cu * 4 waves must be <= 32768)");
   {
     const uint64_t tiles = (uint64_t)((p->width + 7) / 8) * ((p->height + 7) / 8);
-    const uint64_t per_wave = (tiles + r->nwaves - 1) / r->nwaves;  // a wave owns floor or ceil(tiles / nwaves) adjacent tiles
-    if (per_wave * sif >= 65536) return fail(PT_ERR_INVALID_ARGUMENT, "image x samples_in_flight too large for the chunk tables");
-    r->seg_cap = (uint32_t)(per_wave * sif) * 64;
+    r->tiles_per_seg = (uint32_t)((tiles + 32639) / 32640);  // nseg <= 32768 after rounding up to a multiple of the band count
+    if (r->tiles_per_seg_override) r->tiles_per_seg = std::max(r->tiles_per_seg, r->tiles_per_seg_override);
+    r->nseg = (uint32_t)((tiles + r->tiles_per_seg - 1) / r->tiles_per_seg);
+    r->nseg = (r->nseg + r->seg_bands - 1) / r->seg_bands * r->seg_bands;  // (segments past the last tile stay empty)
+    if ((uint64_t)r->tiles_per_seg * sif >= 65536) return fail(PT_ERR_INVALID_ARGUMENT, "image x samples_in_flight too large for the chunk tables");
+    r->seg_cap = r->tiles_per_seg * sif * 64;
+    r->nstats = std::max(r->grid * (kBlock / 64), r->shade_grid * (shade_block_threads() / 64));
   }
-  r->capacity = (size_t)r->nwaves * r->seg_cap;  // >= npix * sif
+  r->capacity = (size_t)r->nseg * r->seg_cap;  // >= npix * sif
   for (int k = 0; k < 2; k++) {
     PT_HIP(r->st_rayO[k].alloc(r->capacity)); PT_HIP(r->st_rayD[k].alloc(r->capacity));
     PT_HIP(r->st_att[k].alloc(r->capacity)); PT_HIP(r->st_pid[k].alloc(r->capacity));
@@ -490,12 +488,12 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
   PT_HIP(r->hit.alloc(r->capacity));
   PT_HIP(r->sq_o.alloc(r->capacity)); PT_HIP(r->sq_d.alloc(r->capacity)); PT_HIP(r->sq_c.alloc(r->capacity));
   PT_HIP(r->Lbuf.alloc((size_t)npix * sif));
-  for (int k = 0; k < 2; k++) PT_HIP(r->seg_active[k].alloc(r->nwaves));
-  PT_HIP(r->seg_shadow.alloc(r->nwaves));
-  PT_HIP(r->wave_stats.alloc(r->nwaves));
+  for (int k = 0; k < 2; k++) PT_HIP(r->seg_active[k].alloc(r->nseg));
+  PT_HIP(r->seg_shadow.alloc(r->nseg));
+  PT_HIP(r->wave_stats.alloc(r->nstats));
   for (int k = 0; k < 2; k++) PT_HIP(r->chunk_table[k].alloc(r->capacity / 64));
   PT_HIP(r->spill.alloc((size_t)r->trace_grid * kBlock * kSpillStack));  // per-thread HBM stack slab behind the LDS stack
-  PT_HIP(hipMemsetAsync(r->wave_stats.p, 0, sizeof(WaveStats) * r->nwaves, r->stream));
+  PT_HIP(hipMemsetAsync(r->wave_stats.p, 0, sizeof(WaveStats) * r->nstats, r->stream));
   if (p->external_accumulator) {
     r->acc = (vec4*)p->external_accumulator;
   } else {

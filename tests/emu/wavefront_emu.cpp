@@ -238,11 +238,7 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
     bool prime = true;
     for (uint32_t d = 2; d * d <= c; d++) if (c % d == 0) { prime = false; break; }
     if (!prime) continue;
-    uint32_t digits = 1;
-    uint64_t chunk = c;
-    while (chunk * c < 65536ull) { chunk *= c; digits++; }
-    const uint64_t M = ~0ull / chunk + 1;
-    e->halton.push_back({(uint32_t)chunk, (uint32_t)(M >> 32), (uint32_t)M, 1.0f / (float)c, (float)c, digits, c, 0u});
+    e->halton.push_back(make_halton_entry(c));
   }
   // flatten to world space (same sequence as lbvh.hip k_flatten)
   std::vector<TriRec> tmp; std::vector<Box3> boxes;
@@ -334,7 +330,7 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
       for (uint32_t b = 0; b < B; b++) {
         TraversalStack st; st.lds = lds.data(); st.pend = pend.data(); st.lds_stride = 1; st.spill = spill.data(); st.spill_stride = 1;
         TraversalCount tc;
-        const float ir = S.has_alpha ? Halton{S.halton, rg.offset, dim}.sample1d() : 0.0f;
+        const float ir = S.has_alpha ? Halton{halton_table(S.halton), rg.offset, dim}.sample1d() : 0.0f;
         RayHit hit = traverse<false, true>(S, o, d, 1e-3f, kInf, ir, st, &tc);
         g_nodes += tc.nodes; g_tris += tc.tris; g_rays++;
         if (hits && hit.tri != kInvalidRef) { hits[((size_t)b * NP + pid) * 2] = S.tris[hit.tri].inst; hits[((size_t)b * NP + pid) * 2 + 1] = S.tris[hit.tri].prim; }
@@ -342,7 +338,8 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
           if (S.env_texture >= 0) L = L + stage_miss(S, d, att, b, lastPdf, lastSpec);
           break;
         }
-        ShadeIn in; in.o = o; in.d = d; in.att = att; in.lastPdf = lastPdf; in.lastSpecular = lastSpec; in.offset = rg.offset;
+        const vec4 qO{o.x, o.y, o.z, lastPdf}, qD{d.x, d.y, d.z, 0.0f};  // the queue entry the stage may re-read
+        ShadeIn in; in.o = o; in.d = d; in.att = att; in.rayO = &qO; in.rayD = &qD; in.lastSpecular = lastSpec; in.offset = rg.offset;
         in.dim = dim + 1; in.bounce = b; in.t = hit.t; in.u = hit.u; in.v = hit.v; in.tri = hit.tri;
         ShadeOut out = stage_shade(S, in);
         if (out.has_emitted) L = L + out.emitted;
@@ -367,7 +364,7 @@ void emu_trace_primary(void* h, uint32_t sample, pt_hit_record* out) {
       RayGenOut rg = stage_raygen(S, x, y, sample);
       TraversalStack st; st.lds = lds.data(); st.pend = pend.data(); st.lds_stride = 1; st.spill = spill.data(); st.spill_stride = 1;
       TraversalCount tc;
-      const float ir = S.has_alpha ? Halton{S.halton, rg.offset, rg.dim}.sample1d() : 0.0f;
+      const float ir = S.has_alpha ? Halton{halton_table(S.halton), rg.offset, rg.dim}.sample1d() : 0.0f;
       RayHit hit = traverse<false, false>(S, rg.o, rg.d, 1e-3f, kInf, ir, st, &tc);
       pt_hit_record& r = out[y * S.width + x];
       if (hit.tri != kInvalidRef) { r.t = hit.t; r.u = hit.u; r.v = hit.v; r.instance = S.tris[hit.tri].inst; r.primitive = S.tris[hit.tri].prim; }
@@ -375,6 +372,6 @@ void emu_trace_primary(void* h, uint32_t sample, pt_hit_record* out) {
     }
 }
 void emu_get_counts(unsigned long long out[3]) { out[0] = g_nodes; out[1] = g_tris; out[2] = g_rays; g_nodes = g_tris = g_rays = 0; }
-float emu_halton(void* h, uint32_t i, uint32_t d) { return halton(((Emu*)h)->halton.data(), i, d); }
+float emu_halton(void* h, uint32_t i, uint32_t d) { return halton(halton_table(((Emu*)h)->halton.data()), i, d); }
 
 }  // extern "C"

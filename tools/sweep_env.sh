@@ -1,13 +1,13 @@
-# usage (GPU box): bash tools/sweep_env.sh VAR v1 v2 ...  — benches C2 and C3 with VAR set to each value
-var=$1; shift
-for v in "$@"; do
-  for w in c2 c3; do
-    env $var=$v timeout -k 10 200 python bench.py --workload $w --no-cpu-baseline --steps 16 > gpurun_out/se_${var}_${v}_$w.json 2>gpurun_out/se.err || exit 1
-  done
-done
+# usage (GPU box): bash tools/sweep_env.sh VAR "v1 v2 ..." [workloads] — default library, one environment knob swept
+VAR=$1; VALS=$2; WLS=${3:-c3}
+for v in $VALS; do for w in $WLS; do
+  env $VAR=$v timeout -k 10 200 python bench.py --workload $w --no-cpu-baseline --steps 4 > gpurun_out/se_${VAR}_${v}_$w.json 2>gpurun_out/se_${VAR}_${v}_$w.err || { echo "$VAR=$v $w FAILED"; tail -3 gpurun_out/se_${VAR}_${v}_$w.err; }
+done; done
 python - <<PY
 import json,glob
-for f in sorted(glob.glob("gpurun_out/se_${var}_*.json")):
-    d=json.load(open(f)); r=d["roofline"]; k=d["extra"]["kernel_ms"]; n=d["steps"]
-    print(f.split("se_")[1][:-5].ljust(28), d["value"], "closest/step %.2f shade/step %.2f shadow/step %.2f" % (k["closest"]/n, k["shade"]/n, k["shadow"]/n), "n/t", r["nodes_per_ray"], r["tris_per_ray"])
+for f in sorted(glob.glob("gpurun_out/se_${VAR}_*.json")):
+    try: d=json.load(open(f))
+    except Exception: continue
+    k=d["extra"]["kernel_ms"]; n=d["steps"]
+    print(f.split("se_")[1][:-5].ljust(30), d["value"], "ms/step %.2f" % d["ms_per_step"], "closest %.2f shade %.2f shadow %.2f raygen %.2f" % (k["closest"]/n, k["shade"]/n, k["shadow"]/n, k["raygen"]/n))
 PY
