@@ -75,6 +75,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline sample")
     ap.add_argument("--inproc", action="store_true", help="N > 1: one process, the library's own multi-device path")
+    ap.add_argument("--devices", default="", help="--inproc: explicit HIP ordinals, e.g. 0,0 = two logical shards on one GPU (rehearsal)")
     ap.add_argument("--pmc-pass", action="store_true",
                     help="under rocprofv3 --pmc: only full-size batches (no warm-up, no instrumented sample, no CPU leg, no event timing)")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the second (event-timed) pass")
@@ -206,7 +207,10 @@ def main():
     n_gpus = args.gpus if inproc else world
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)  # the accumulator lives in a torch tensor so RCCL can reduce it
 
-    r = Renderer(devices=list(range(ndev))) if inproc else Renderer(device=local_rank)
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(ndev))
+    if inproc and len(devices) != ndev:
+        raise SystemExit("--devices must list --gpus ordinals")
+    r = Renderer(devices=devices) if inproc else Renderer(device=local_rank)
     # samples of this process: K*S per device, timed; the warm-up renders (and discards) W*S of the same range first
     total_spp = K * S * ndev
     first, _ = shard_samples(rank, world, total_spp)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2u
+#define PT_ABI_VERSION 3u
 
 /* ---------------------------------------------------------------------------------------------------------- */
 /* Enums (same numeric values as the reference)                                                                 */
@@ -220,9 +220,22 @@ typedef struct pt_create_info {
   const void* lut_blob;   /* the LUT blob (tools/make_lut_blob.py) in host memory, or NULL ... */
   uint64_t lut_blob_size;
   const char* lut_path;   /* ... to read it from this file (NULL: $PTAMD_LUT_PATH) */
+  /* NEW (ABI 3): a DEVICE GROUP.  device_count >= 2 devices share every render: the samples [first_sample, first_sample + spp)
+   * are dealt to them in contiguous ranges (whole GMoN buckets with PT_FLAG_GMON), each device renders its range on its own
+   * host thread and stream, and the running means are merged when the image is asked for (pt_wait / pt_read_*): ONE RCCL
+   * all-reduce of the float accumulator over xGMI (bucket means gathered to the first device and resolved there with GMoN).
+   * The merged image lives on device_ordinals[0] (in external_accumulator when given).  A device may be listed more than
+   * once (logical shards on one GPU).  device_count == 0: the single device `device_ordinal`. */
+  const int32_t* device_ordinals;
+  uint32_t device_count;
 } pt_create_info;
 
 int pt_create(const pt_create_info* info, pt_renderer** out);
+/* How a device group deals the samples [0, spp) of a render to its `members` (pure host arithmetic, exported for tests):
+ * contiguous ranges, equal up to one sample; with PT_FLAG_GMON whole buckets per member (bucket b = samples
+ * [b * ceil(spp / buckets), ...), renderer_pt.cpp:124-126), bucket0/bucket1 = each member's bucket range (may be NULL). */
+int pt_group_partition(uint32_t spp, uint32_t members, int32_t flags, uint32_t gmon_buckets, uint64_t* first, uint64_t* count,
+                       uint32_t* bucket0, uint32_t* bucket1);
 /* Renderer::~Renderer (renderer_pt.hpp:34) */
 void pt_destroy(pt_renderer* r);
 

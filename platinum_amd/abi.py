@@ -7,7 +7,7 @@ library is missing or cannot find a device, loading / pt_create raises.
 import ctypes as C
 import os
 
-PT_ABI_VERSION = 2
+PT_ABI_VERSION = 3
 
 # renderer_pt.hpp:21-26
 STATUS_BLOCKED, STATUS_READY, STATUS_BUSY, STATUS_DONE = 0, 1, 4, 8
@@ -119,6 +119,7 @@ class CreateInfo(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("device_ordinal", C.c_int32), ("lut_blob", C.c_void_p),
         ("lut_blob_size", C.c_uint64), ("lut_path", C.c_char_p),
+        ("device_ordinals", C.POINTER(C.c_int32)), ("device_count", C.c_uint32),
     ]
 
 
@@ -183,6 +184,8 @@ assert C.sizeof(AreaLight) == 48
 # every symbol include/ptamd.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("pt_create", C.c_int, [C.POINTER(CreateInfo), C.POINTER(C.c_void_p)]),
+    ("pt_group_partition", C.c_int, [C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                     C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("pt_destroy", None, [C.c_void_p]),
     ("pt_start_render", C.c_int, [C.c_void_p, C.POINTER(SceneSnapshot), C.POINTER(RenderParams)]),
     ("pt_render_step", C.c_int, [C.c_void_p, C.c_uint32]),

@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(vec4* __restrict__ acc, c
 // (kernel.metal:675-681 — note: NOT the sample's index inside its bucket; reproduced as is).
 __global__ void __launch_bounds__(kBlock) k_accumulate_gmon(vec4* __restrict__ buckets, const vec4* __restrict__ Lbuf,
                                                              uint32_t npixels, uint32_t nsamples, uint32_t n0,
-                                                             uint32_t samples_per_bucket, uint32_t gmon_buckets,
+                                                             uint32_t samples_per_bucket, uint32_t gmon_buckets, uint32_t bucket_base,
                                                              uint32_t nonfinite_policy, BatchCounters* __restrict__ ctr) {
   const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= npixels) return;
@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(kBlock) k_accumulate_gmon(vec4* __restrict__ b
       if (nonfinite_policy == PT_NONFINITE_ZERO) L = v3(0.0f);
     }
     const uint32_t f = n0 + s;
-    vec4* acc = buckets + (size_t)(f / samples_per_bucket) * npixels;
+    vec4* acc = buckets + (size_t)(f / samples_per_bucket - bucket_base) * npixels;  // (bucket_base: the buckets[] of a device-group member starts there)
     const uint32_t localFrameIdx = f / gmon_buckets;
     if (localFrameIdx > 0) {
       const vec4 a = acc[p];
@@ -623,6 +623,18 @@ __global__ void __launch_bounds__(kBlock) k_gmon(vec4* __restrict__ acc, const v
   for (int i = c; i < (int)nBuckets - c; i++) sum = sum + values[i];
   const vec3 color = sum / (float)((int)nBuckets - 2 * c);
   acc[p] = vec4{color.x, color.y, color.z, 1.0f};
+}
+
+// ---- device-group merge (multi_device.hip): weighted sum of the members' running means ------------------------------------
+__global__ void __launch_bounds__(kBlock) k_weighted_add(vec4* __restrict__ out, const vec4* __restrict__ in, float w, uint32_t npixels,
+                                                          uint32_t first, uint32_t last) {
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= npixels) return;
+  const vec4 a = in[p];
+  vec4 o = first ? vec4{0.0f, 0.0f, 0.0f, 0.0f} : out[p];
+  o.x += w * a.x; o.y += w * a.y; o.z += w * a.z;
+  o.w = last ? 1.0f : 0.0f;
+  out[p] = o;
 }
 
 // ---- post-process + tonemap -> RGBA8 (pt_post.h) ------------------------------------------------------------
@@ -730,9 +742,12 @@ void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npix
                      nonfinite_policy, ctr);
 }
 void launch_accumulate_gmon(hipStream_t s, vec4* buckets, const vec4* Lbuf, uint32_t npixels, uint32_t nsamples, uint32_t n0,
-                            uint32_t samples_per_bucket, uint32_t gmon_buckets, uint32_t nonfinite_policy, BatchCounters* ctr) {
+                            uint32_t samples_per_bucket, uint32_t gmon_buckets, uint32_t bucket_base, uint32_t nonfinite_policy, BatchCounters* ctr) {
   hipLaunchKernelGGL(k_accumulate_gmon, dim3((npixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, buckets, Lbuf, npixels, nsamples, n0,
-                     samples_per_bucket, gmon_buckets, nonfinite_policy, ctr);
+                     samples_per_bucket, gmon_buckets, bucket_base, nonfinite_policy, ctr);
+}
+void launch_weighted_add(hipStream_t s, vec4* out, const vec4* in, float w, uint32_t npixels, bool first, bool last) {
+  hipLaunchKernelGGL(k_weighted_add, dim3((npixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, out, in, w, npixels, first ? 1u : 0u, last ? 1u : 0u);
 }
 void launch_gmon(hipStream_t s, vec4* acc, const vec4* buckets, uint32_t npixels, uint32_t nBuckets, float cap) {
   hipLaunchKernelGGL(k_gmon, dim3((npixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, acc, buckets, npixels, nBuckets, cap);

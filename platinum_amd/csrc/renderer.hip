@@ -18,146 +18,18 @@
 #include <string>
 #include <vector>
 
-#include "host_scene.h"
-#include "kernels.h"
-#include "pt_bvh.h"
+#include "renderer_state.h"
 
 using namespace pt;
 
 namespace {
-
 thread_local std::string g_last_error;
-
-int fail(int code, const std::string& msg) {
+}
+int pt_fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
 }
-
-#define PT_HIP(call)                                                                                       \
-  do {                                                                                                     \
-    hipError_t e_ = (call);                                                                                \
-    if (e_ != hipSuccess) {                                                                                \
-      char buf_[512];                                                                                      \
-      snprintf(buf_, sizeof(buf_), "%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
-      return fail(e_ == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP, buf_);                     \
-    }                                                                                                      \
-  } while (0)
-
-template <typename T>
-struct DevBuf {
-  T* p = nullptr;
-  size_t n = 0;
-  hipError_t alloc(size_t count) {
-    release();
-    n = count;
-    if (count == 0) return hipSuccess;
-    return hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * count);
-  }
-  hipError_t upload(const std::vector<T>& v) {
-    hipError_t e = alloc(v.size());
-    if (e != hipSuccess || v.empty()) return e;
-    return hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice);
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    n = 0;
-  }
-  ~DevBuf() { release(); }
-};
-
-enum KernelClass { K_RAYGEN = 0, K_CLOSEST, K_SHADE, K_SHADOW, K_ACCUM, K_CLASSES };
-
-struct TimedLaunch { int cls; hipEvent_t start, stop; };
-
-}  // namespace
-
-struct pt_renderer {
-  int device = 0;
-  int num_cu = 256;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
-
-  // create-time tables
-  DevBuf<float> lut_data;
-  LutSet luts{};
-  uint32_t lut_w_E = 0, lut_w_Eavg = 0;
-  DevBuf<HaltonEntry> halton;
-
-  // scene (valid after pt_start_render)
-  bool started = false;
-  DevBuf<pt_float3> positions;
-  DevBuf<pt_vertex_data> vdata;
-  DevBuf<uint32_t> indices, slots;
-  DevBuf<MeshInfo> meshes;
-  DevBuf<InstanceInfo> instances;
-  DevBuf<pt_material_gpu> materials;
-  DevBuf<pt_area_light> lights_d;
-  std::vector<pt_area_light> lights;
-  DevBuf<DeviceScene> scene_d;
-  DevBuf<ShadeRec> shade_recs;
-  DevBuf<vec4> tex_pixels;            // all textures decoded to linear float4 (host_scene.h decode_textures)
-  DevBuf<TexInfo> textures;
-  DevBuf<pt_alias_entry> env_alias_d;
-  std::vector<pt_alias_entry> env_alias;
-  LbvhResult bvh{};
-  DeviceScene S{};
-  pt_render_params params{};
-  pt_constants constants{};
-  uint32_t instance_count = 0, tri_count = 0;
-
-  // wavefront buffers
-  uint32_t samples_in_flight = 0;
-  size_t capacity = 0;  // path slots
-  DevBuf<vec4> st_rayO[2], st_rayD[2], st_att[2], hit, sq_o, sq_d, sq_c, Lbuf, acc_own;
-  DevBuf<uint32_t> st_pid[2], spill, seg_active[2], seg_shadow;
-  DevBuf<WaveStats> wave_stats;
-  DevBuf<uint32_t> chunk_table[2];
-  DevBuf<vec4> gmon_buckets_d;  // [bucket][pixel] with PT_FLAG_GMON (renderer_pt.cpp:824-830)
-  float gmon_cap = 1.0f;        // GmonOptions.cap (pt_shader_defs.hpp:164-166)
-  pt_post_options post{};
-  pt_tonemap_options tonemap{};
-  DevBuf<uint32_t> render_target;  // RGBA8 (renderer_pt.cpp:832-835)
-  uint32_t trace_grid = 0, trace_blocks_per_cu = PT_TRACE_WAVES;
-  uint32_t nseg = 0, tiles_per_seg = 1, seg_bands = 4, tiles_per_seg_override = 0, nstats = 0, seg_cap = 0, blocks_per_cu = 6, shade_grid = 0, refill_threshold = 48;
-  DevBuf<BatchCounters> ctr;
-  DevBuf<Totals> totals;
-  vec4* acc = nullptr;
-  uint32_t grid = 0;
-
-  // progress (renderer_pt.hpp:168-171)
-  uint64_t accumulated = 0, total = 0;
-  std::chrono::steady_clock::time_point render_start;
-  uint64_t timer_ms = 0;
-
-  // measurement
-  bool profiling = false;
-  std::vector<TimedLaunch> timed;
-  double ms_class[K_CLASSES] = {0, 0, 0, 0, 0};
-  uint64_t launches[K_CLASSES] = {0, 0, 0, 0, 0};
-  double upload_ms = 0, bvh_ms = 0;
-
-  PathState path_state(int k) { return PathState{st_rayO[k].p, st_rayD[k].p, st_att[k].p, st_pid[k].p}; }
-  ShadowQueue shadow_queue() { return ShadowQueue{sq_o.p, sq_d.p, sq_c.p}; }
-  Segments segments() { return Segments{{seg_active[0].p, seg_active[1].p}, seg_shadow.p, wave_stats.p, chunk_table[0].p, chunk_table[1].p, seg_cap, nseg, tiles_per_seg, seg_bands, nstats, refill_threshold}; }
-
-  void free_scene() {
-    positions.release(); vdata.release(); indices.release(); slots.release(); meshes.release(); instances.release();
-    materials.release(); lights_d.release(); tex_pixels.release(); textures.release(); env_alias_d.release(); scene_d.release(); shade_recs.release();
-    if (bvh.nodes) (void)hipFree(bvh.nodes);
-    if (bvh.tris) (void)hipFree(bvh.tris);
-    bvh = LbvhResult{};
-    for (int k = 0; k < 2; k++) { st_rayO[k].release(); st_rayD[k].release(); st_att[k].release(); st_pid[k].release(); }
-    seg_active[0].release(); seg_active[1].release(); seg_shadow.release(); wave_stats.release(); chunk_table[0].release(); chunk_table[1].release(); gmon_buckets_d.release(); render_target.release();
-    hit.release(); sq_o.release(); sq_d.release(); sq_c.release(); Lbuf.release(); acc_own.release(); spill.release();
-    acc = nullptr;
-    started = false;
-  }
-  void drop_timed() {
-    for (auto& t : timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
-    timed.clear();
-  }
-};
+const std::string& pt_last_error_string() { return g_last_error; }
 
 namespace {
 
@@ -216,11 +88,13 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
     const uint32_t npix = S.width * S.height;
     if (r->params.flags & PT_FLAG_GMON) {
       const uint32_t buckets = r->params.gmon_buckets;
-      const uint32_t spb = (r->params.spp + buckets - 1) / buckets;  // renderer_pt.cpp:124-125
-      launch_accumulate_gmon(s, r->gmon_buckets_d.p, r->Lbuf.p, npix, ns, n0, spb, buckets, r->params.nonfinite_policy, ctr);
+      const uint32_t total_spp = r->gmon_total_spp ? r->gmon_total_spp : r->params.spp;
+      const uint32_t spb = (total_spp + buckets - 1) / buckets;  // renderer_pt.cpp:124-125
+      const uint32_t f0 = n0 + r->gmon_sample_base;              // (a member of a device group: index within the whole render)
+      launch_accumulate_gmon(s, r->gmon_buckets_d.p, r->Lbuf.p, npix, ns, f0, spb, buckets, r->gmon_bucket_base, r->params.nonfinite_policy, ctr);
       // the reference resolves after every frame with fullBuckets = gmonIdx + 1 (renderer_pt.cpp:164-179); only the last
       // resolve of a batch is observable
-      launch_gmon(s, r->acc, r->gmon_buckets_d.p, npix, (n0 + ns - 1) / spb + 1, r->gmon_cap);
+      launch_gmon(s, r->acc, r->gmon_buckets_d.p, npix, (f0 + ns - 1) / spb + 1 - r->gmon_bucket_base, r->gmon_cap);
     } else {
       launch_accumulate(s, r->acc, r->Lbuf.p, npix, ns, n0, r->params.nonfinite_policy, ctr);
     }
@@ -287,23 +161,21 @@ int build_halton_table(pt_renderer* r) {
 
 }  // namespace
 
-extern "C" {
+extern "C" const char* pt_last_error(void) { return g_last_error.c_str(); }
 
-const char* pt_last_error(void) { return g_last_error.c_str(); }
-
-int pt_create(const pt_create_info* info, pt_renderer** out) {
+int dev_create(const pt_create_info* info, int device_ordinal, pt_renderer** out) {
   if (!info || !out) return fail(PT_ERR_INVALID_ARGUMENT, "pt_create: null argument");
   *out = nullptr;
   if (info->abi_version != PT_ABI_VERSION) return fail(PT_ERR_INVALID_ARGUMENT, "pt_create: ABI version mismatch");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(PT_ERR_NO_DEVICE, "pt_create: no HIP device available (this library has no CPU fallback)");
-  if (info->device_ordinal < 0 || info->device_ordinal >= ndev) return fail(PT_ERR_INVALID_ARGUMENT, "pt_create: bad device ordinal");
-  PT_HIP(hipSetDevice(info->device_ordinal));
+  if (device_ordinal < 0 || device_ordinal >= ndev) return fail(PT_ERR_INVALID_ARGUMENT, "pt_create: bad device ordinal");
+  PT_HIP(hipSetDevice(device_ordinal));
   auto* r = new pt_renderer();
   pt_default_post_options(&r->post);
   pt_default_tonemap_options(&r->tonemap);
-  r->device = info->device_ordinal;
+  r->device = device_ordinal;
   if (const char* e = getenv("PTAMD_REFILL")) r->refill_threshold = (uint32_t)atoi(e);
   if (const char* e = getenv("PTAMD_TILES_PER_SEG")) r->tiles_per_seg_override = (uint32_t)std::max(0, atoi(e));  // tuning knobs
   if (const char* e = getenv("PTAMD_SEG_BANDS")) r->seg_bands = (uint32_t)std::max(1, std::min(64, atoi(e)));
@@ -336,12 +208,12 @@ int pt_create(const pt_create_info* info, pt_renderer** out) {
     if ((rc = build_halton_table(r)) != PT_OK) break;
     if (r->ctr.alloc(1) != hipSuccess || r->totals.alloc(2) != hipSuccess) { rc = fail(PT_ERR_OUT_OF_MEMORY, "counter allocation failed"); break; }
   } while (0);
-  if (rc != PT_OK) { pt_destroy(r); return rc; }
+  if (rc != PT_OK) { dev_destroy(r); return rc; }
   *out = r;
   return PT_OK;
 }
 
-void pt_destroy(pt_renderer* r) {
+void dev_destroy(pt_renderer* r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
   if (r->stream) (void)hipStreamSynchronize(r->stream);
@@ -351,7 +223,7 @@ void pt_destroy(pt_renderer* r) {
   delete r;
 }
 
-int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_render_params* p) {
+int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_render_params* p) {
   if (!r || !scene || !p) return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: null argument");
   if (p->width == 0 || p->height == 0 || p->spp == 0) return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: empty size or spp");
   if (p->max_bounces < 1 || p->max_bounces > 50)
@@ -501,8 +373,9 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
     r->acc = r->acc_own.p;
   }
   if (p->flags & PT_FLAG_GMON) {
-    PT_HIP(r->gmon_buckets_d.alloc((size_t)npix * p->gmon_buckets));
-    PT_HIP(hipMemsetAsync(r->gmon_buckets_d.p, 0, sizeof(vec4) * npix * p->gmon_buckets, r->stream));
+    const uint32_t own = r->gmon_own_buckets ? r->gmon_own_buckets : p->gmon_buckets;
+    PT_HIP(r->gmon_buckets_d.alloc((size_t)npix * own));
+    PT_HIP(hipMemsetAsync(r->gmon_buckets_d.p, 0, sizeof(vec4) * npix * own, r->stream));
   }
   PT_HIP(hipMemsetAsync(r->acc, 0, sizeof(vec4) * npix, r->stream));
   PT_HIP(hipMemsetAsync(r->totals.p, 0, sizeof(Totals), r->stream));
@@ -517,7 +390,7 @@ int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_ren
   return PT_OK;
 }
 
-int pt_render_step(pt_renderer* r, uint32_t max_spp) {
+int dev_render_step(pt_renderer* r, uint32_t max_spp) {
   if (!r) return fail(PT_ERR_INVALID_ARGUMENT, "null renderer");
   if (!r->started) return fail(PT_ERR_BAD_STATE, "pt_render_step before pt_start_render");
   PT_HIP(hipSetDevice(r->device));
@@ -534,7 +407,7 @@ int pt_render_step(pt_renderer* r, uint32_t max_spp) {
   return PT_OK;
 }
 
-int pt_wait(pt_renderer* r) {
+int dev_wait(pt_renderer* r) {
   if (!r) return fail(PT_ERR_INVALID_ARGUMENT, "null renderer");
   PT_HIP(hipSetDevice(r->device));
   PT_HIP(hipStreamSynchronize(r->stream));
@@ -544,7 +417,7 @@ int pt_wait(pt_renderer* r) {
   return PT_OK;
 }
 
-int pt_status(const pt_renderer* r) {  // renderer_pt.cpp:1023-1031
+int dev_status(const pt_renderer* r) {  // renderer_pt.cpp:1023-1031
   if (!r) return PT_STATUS_BLOCKED;
   if (r->started && r->accumulated < r->total) return PT_STATUS_BUSY;
   int st = PT_STATUS_READY;
@@ -552,32 +425,32 @@ int pt_status(const pt_renderer* r) {  // renderer_pt.cpp:1023-1031
   return st;
 }
 
-int pt_progress(const pt_renderer* r, uint64_t* accumulated, uint64_t* total) {
+int dev_progress(const pt_renderer* r, uint64_t* accumulated, uint64_t* total) {
   if (!r || !accumulated || !total) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   *accumulated = r->accumulated;
   *total = r->total;
   return PT_OK;
 }
 
-uint64_t pt_render_time_ms(const pt_renderer* r) { return r ? r->timer_ms : 0; }
+uint64_t dev_render_time_ms(const pt_renderer* r) { return r ? r->timer_ms : 0; }
 
-int pt_read_accumulator(pt_renderer* r, float* rgba_out) {
+int dev_read_accumulator(pt_renderer* r, float* rgba_out) {
   if (!r || !rgba_out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   if (!r->started) return fail(PT_ERR_BAD_STATE, "pt_read_accumulator before pt_start_render");
-  int rc = pt_wait(r);
+  int rc = dev_wait(r);
   if (rc != PT_OK) return rc;
   PT_HIP(hipMemcpy(rgba_out, r->acc, sizeof(vec4) * (size_t)r->S.width * r->S.height, hipMemcpyDeviceToHost));
   return PT_OK;
 }
 
-void pt_default_post_options(pt_post_options* o) {  // core/postprocessing.hpp:168-198
+extern "C" void pt_default_post_options(pt_post_options* o) {  // core/postprocessing.hpp:168-198
   if (!o) return;
   memset(o, 0, sizeof(*o));
   o->ca_green_shift = 70.0f;
   o->vig_feather = 50.0f; o->vig_power = 20.0f; o->vig_roundness = 100.0f;
 }
 
-void pt_default_tonemap_options(pt_tonemap_options* o) {  // postprocessing.hpp:29-160, 209-226
+extern "C" void pt_default_tonemap_options(pt_tonemap_options* o) {  // postprocessing.hpp:29-160, 209-226
   if (!o) return;
   memset(o, 0, sizeof(*o));
   o->tonemapper = PT_TONEMAP_AGX;
@@ -600,24 +473,21 @@ void pt_default_tonemap_options(pt_tonemap_options* o) {  // postprocessing.hpp:
   for (int k = 0; k < 2; k++) { o->output_space.r[k] = p3[0][k]; o->output_space.g[k] = p3[1][k]; o->output_space.b[k] = p3[2][k]; o->output_space.w[k] = p3[3][k]; }
 }
 
-int pt_set_post_options(pt_renderer* r, const pt_post_options* o) {
+int dev_set_post_options(pt_renderer* r, const pt_post_options* o) {
   if (!r || !o) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   r->post = *o;
   return PT_OK;
 }
 
-int pt_set_tonemap_options(pt_renderer* r, const pt_tonemap_options* o) {
+int dev_set_tonemap_options(pt_renderer* r, const pt_tonemap_options* o) {
   if (!r || !o) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   if (o->tonemapper > PT_TONEMAP_FLIM) return fail(PT_ERR_INVALID_ARGUMENT, "bad tonemapper");
   r->tonemap = *o;
   return PT_OK;
 }
 
-int pt_read_render_target(pt_renderer* r, uint8_t* rgba8_out) {
-  if (!r || !rgba8_out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
-  if (!r->started) return fail(PT_ERR_BAD_STATE, "pt_read_render_target before pt_start_render");
-  int rc = pt_wait(r);
-  if (rc != PT_OK) return rc;
+int dev_postprocess_to_host(pt_renderer* r, const vec4* acc_device, uint8_t* rgba8_out) {
+  PT_HIP(hipSetDevice(r->device));
   const size_t npix = (size_t)r->S.width * r->S.height;
   if (r->render_target.n != npix) PT_HIP(r->render_target.alloc(npix));
   PostConstants pc;
@@ -625,39 +495,50 @@ int pt_read_render_target(pt_renderer* r, uint8_t* rgba8_out) {
   pc.tm = r->tonemap;
   const Mat3 odt = compute_transform(r->params.working_space, r->tonemap.output_space);  // renderer_pt.cpp:190-191
   pc.odt = PPMat3{odt.c0, odt.c1, odt.c2};
-  launch_postprocess(r->stream, r->acc, r->render_target.p, r->S.width, r->S.height, pc);
+  launch_postprocess(r->stream, acc_device, r->render_target.p, r->S.width, r->S.height, pc);
   PT_HIP(hipGetLastError());
   PT_HIP(hipStreamSynchronize(r->stream));
   PT_HIP(hipMemcpy(rgba8_out, r->render_target.p, npix * 4, hipMemcpyDeviceToHost));
   return PT_OK;
 }
 
-int pt_set_gmon_options(pt_renderer* r, const pt_gmon_options* o) {
+int dev_read_render_target(pt_renderer* r, uint8_t* rgba8_out) {
+  if (!r || !rgba8_out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!r->started) return fail(PT_ERR_BAD_STATE, "pt_read_render_target before pt_start_render");
+  int rc = dev_wait(r);
+  if (rc != PT_OK) return rc;
+  return dev_postprocess_to_host(r, r->acc, rgba8_out);
+}
+
+int dev_set_gmon_options(pt_renderer* r, const pt_gmon_options* o) {
   if (!r || !o) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   r->gmon_cap = o->cap;
   return PT_OK;
 }
 
-int pt_read_gmon_bucket(pt_renderer* r, uint32_t bucket, float* rgba_out) {
+int dev_read_gmon_bucket(pt_renderer* r, uint32_t bucket, float* rgba_out) {
   if (!r || !rgba_out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
-  if (!r->started || !(r->params.flags & PT_FLAG_GMON) || bucket >= r->params.gmon_buckets) return fail(PT_ERR_BAD_STATE, "no such GMoN bucket");
-  int rc = pt_wait(r);
+  const uint32_t own = r->gmon_own_buckets ? r->gmon_own_buckets : r->params.gmon_buckets;
+  if (!r->started || !(r->params.flags & PT_FLAG_GMON) || bucket < r->gmon_bucket_base || bucket - r->gmon_bucket_base >= own)
+    return fail(PT_ERR_BAD_STATE, "no such GMoN bucket");
+  bucket -= r->gmon_bucket_base;
+  int rc = dev_wait(r);
   if (rc != PT_OK) return rc;
   const size_t npix = (size_t)r->S.width * r->S.height;
   PT_HIP(hipMemcpy(rgba_out, r->gmon_buckets_d.p + npix * bucket, sizeof(vec4) * npix, hipMemcpyDeviceToHost));
   return PT_OK;
 }
 
-void* pt_accumulator_device_ptr(pt_renderer* r) { return (r && r->started) ? (void*)r->acc : nullptr; }
+void* dev_accumulator_device_ptr(pt_renderer* r) { return (r && r->started) ? (void*)r->acc : nullptr; }
 
-int pt_get_constants(const pt_renderer* r, pt_constants* out) {
+int dev_get_constants(const pt_renderer* r, pt_constants* out) {
   if (!r || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
   *out = r->constants;
   return PT_OK;
 }
 
-int pt_get_lights(const pt_renderer* r, pt_area_light* out, uint32_t capacity, uint32_t* count) {
+int dev_get_lights(const pt_renderer* r, pt_area_light* out, uint32_t capacity, uint32_t* count) {
   if (!r || !count) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
   *count = (uint32_t)r->lights.size();
@@ -666,7 +547,7 @@ int pt_get_lights(const pt_renderer* r, pt_area_light* out, uint32_t capacity, u
   return PT_OK;
 }
 
-int pt_get_env_alias(const pt_renderer* r, pt_alias_entry* out, uint64_t capacity, uint64_t* count) {
+int dev_get_env_alias(const pt_renderer* r, pt_alias_entry* out, uint64_t capacity, uint64_t* count) {
   if (!r || !count) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
   *count = r->env_alias.size();
@@ -675,7 +556,7 @@ int pt_get_env_alias(const pt_renderer* r, pt_alias_entry* out, uint64_t capacit
   return PT_OK;
 }
 
-int pt_trace_primary(pt_renderer* r, uint32_t sample_idx, pt_hit_record* out) {
+int dev_trace_primary(pt_renderer* r, uint32_t sample_idx, pt_hit_record* out) {
   if (!r || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
   PT_HIP(hipSetDevice(r->device));
@@ -695,7 +576,7 @@ int pt_trace_primary(pt_renderer* r, uint32_t sample_idx, pt_hit_record* out) {
   return PT_OK;
 }
 
-int pt_debug_sample(pt_renderer* r, uint32_t sample_idx, float* radiance_out, int32_t* hits_out) {
+int dev_debug_sample(pt_renderer* r, uint32_t sample_idx, float* radiance_out, int32_t* hits_out) {
   if (!r) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
   PT_HIP(hipSetDevice(r->device));
@@ -714,7 +595,7 @@ int pt_debug_sample(pt_renderer* r, uint32_t sample_idx, float* radiance_out, in
   return PT_OK;
 }
 
-int pt_measure_traversal(pt_renderer* r, uint32_t sample_idx) {
+int dev_measure_traversal(pt_renderer* r, uint32_t sample_idx) {
   if (!r) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
   PT_HIP(hipSetDevice(r->device));
@@ -727,16 +608,16 @@ int pt_measure_traversal(pt_renderer* r, uint32_t sample_idx) {
   return PT_OK;
 }
 
-int pt_set_profiling(pt_renderer* r, int enabled) {
+int dev_set_profiling(pt_renderer* r, int enabled) {
   if (!r) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   r->profiling = enabled != 0;
   return PT_OK;
 }
 
-int pt_get_stats(pt_renderer* r, pt_stats* out) {
+int dev_get_stats(pt_renderer* r, pt_stats* out) {
   if (!r || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
-  int rc = pt_wait(r);
+  int rc = dev_wait(r);
   if (rc != PT_OK) return rc;
   Totals t{};
   PT_HIP(hipMemcpy(&t, r->totals.p, sizeof(Totals), hipMemcpyDeviceToHost));
@@ -767,4 +648,3 @@ int pt_get_stats(pt_renderer* r, pt_stats* out) {
   return PT_OK;
 }
 
-}  // extern "C"

@@ -1,0 +1,181 @@
+// renderer_state.h — private state of one `pt_renderer` (shared by renderer.hip: the single-device driver behind the C ABI,
+// and multi_device.hip: the device group that shards samples over several of them).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "host_scene.h"
+#include "kernels.h"
+#include "pt_bvh.h"
+
+using namespace pt;
+
+int pt_fail(int code, const std::string& msg);          // records the message for pt_last_error() (thread-local), returns code
+const std::string& pt_last_error_string();
+inline int fail(int code, const std::string& msg) { return pt_fail(code, msg); }
+
+namespace {
+
+#define PT_HIP(call)                                                                                       \
+  do {                                                                                                     \
+    hipError_t e_ = (call);                                                                                \
+    if (e_ != hipSuccess) {                                                                                \
+      char buf_[512];                                                                                      \
+      snprintf(buf_, sizeof(buf_), "%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return fail(e_ == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP, buf_);                     \
+    }                                                                                                      \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * count);
+  }
+  hipError_t upload(const std::vector<T>& v) {
+    hipError_t e = alloc(v.size());
+    if (e != hipSuccess || v.empty()) return e;
+    return hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice);
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { release(); }
+};
+
+enum KernelClass { K_RAYGEN = 0, K_CLOSEST, K_SHADE, K_SHADOW, K_ACCUM, K_CLASSES };
+
+struct TimedLaunch { int cls; hipEvent_t start, stop; };
+
+}  // namespace
+
+struct pt_renderer {
+  int device = 0;
+  int num_cu = 256;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+
+  // create-time tables
+  DevBuf<float> lut_data;
+  LutSet luts{};
+  uint32_t lut_w_E = 0, lut_w_Eavg = 0;
+  DevBuf<HaltonEntry> halton;
+
+  // scene (valid after pt_start_render)
+  bool started = false;
+  DevBuf<pt_float3> positions;
+  DevBuf<pt_vertex_data> vdata;
+  DevBuf<uint32_t> indices, slots;
+  DevBuf<MeshInfo> meshes;
+  DevBuf<InstanceInfo> instances;
+  DevBuf<pt_material_gpu> materials;
+  DevBuf<pt_area_light> lights_d;
+  std::vector<pt_area_light> lights;
+  DevBuf<DeviceScene> scene_d;
+  DevBuf<ShadeRec> shade_recs;
+  DevBuf<vec4> tex_pixels;            // all textures decoded to linear float4 (host_scene.h decode_textures)
+  DevBuf<TexInfo> textures;
+  DevBuf<pt_alias_entry> env_alias_d;
+  std::vector<pt_alias_entry> env_alias;
+  LbvhResult bvh{};
+  DeviceScene S{};
+  pt_render_params params{};
+  pt_constants constants{};
+  uint32_t instance_count = 0, tri_count = 0;
+
+  // wavefront buffers
+  uint32_t samples_in_flight = 0;
+  size_t capacity = 0;  // path slots
+  DevBuf<vec4> st_rayO[2], st_rayD[2], st_att[2], hit, sq_o, sq_d, sq_c, Lbuf, acc_own;
+  DevBuf<uint32_t> st_pid[2], spill, seg_active[2], seg_shadow;
+  DevBuf<WaveStats> wave_stats;
+  DevBuf<uint32_t> chunk_table[2];
+  DevBuf<vec4> gmon_buckets_d;  // [bucket][pixel] with PT_FLAG_GMON (renderer_pt.cpp:824-830)
+  float gmon_cap = 1.0f;        // GmonOptions.cap (pt_shader_defs.hpp:164-166)
+  pt_post_options post{};
+  pt_tonemap_options tonemap{};
+  DevBuf<uint32_t> render_target;  // RGBA8 (renderer_pt.cpp:832-835)
+  uint32_t trace_grid = 0, trace_blocks_per_cu = PT_TRACE_WAVES;
+  uint32_t nseg = 0, tiles_per_seg = 1, seg_bands = 4, tiles_per_seg_override = 0, nstats = 0, seg_cap = 0, blocks_per_cu = 6, shade_grid = 0, refill_threshold = 48;
+  DevBuf<BatchCounters> ctr;
+  DevBuf<Totals> totals;
+  vec4* acc = nullptr;
+  uint32_t grid = 0;
+
+  // ---- member of a device group (multi_device.hip): where this renderer's samples sit in the whole render ----
+  uint32_t gmon_sample_base = 0;   // index of its first sample relative to the render's first sample (GMoN bucket + weight use the global index)
+  uint32_t gmon_total_spp = 0;     // spp of the whole render (bucket size = ceil(spp / buckets)); 0 = params.spp
+  uint32_t gmon_bucket_base = 0;   // first bucket it owns; its bucket array starts there
+  uint32_t gmon_own_buckets = 0;   // buckets it owns; 0 = params.gmon_buckets
+  struct DeviceGroup* group = nullptr;  // non-null on the front object of a device group
+
+  // progress (renderer_pt.hpp:168-171)
+  uint64_t accumulated = 0, total = 0;
+  std::chrono::steady_clock::time_point render_start;
+  uint64_t timer_ms = 0;
+
+  // measurement
+  bool profiling = false;
+  std::vector<TimedLaunch> timed;
+  double ms_class[K_CLASSES] = {0, 0, 0, 0, 0};
+  uint64_t launches[K_CLASSES] = {0, 0, 0, 0, 0};
+  double upload_ms = 0, bvh_ms = 0;
+
+  PathState path_state(int k) { return PathState{st_rayO[k].p, st_rayD[k].p, st_att[k].p, st_pid[k].p}; }
+  ShadowQueue shadow_queue() { return ShadowQueue{sq_o.p, sq_d.p, sq_c.p}; }
+  Segments segments() { return Segments{{seg_active[0].p, seg_active[1].p}, seg_shadow.p, wave_stats.p, chunk_table[0].p, chunk_table[1].p, seg_cap, nseg, tiles_per_seg, seg_bands, nstats, refill_threshold}; }
+
+  void free_scene() {
+    positions.release(); vdata.release(); indices.release(); slots.release(); meshes.release(); instances.release();
+    materials.release(); lights_d.release(); tex_pixels.release(); textures.release(); env_alias_d.release(); scene_d.release(); shade_recs.release();
+    if (bvh.nodes) (void)hipFree(bvh.nodes);
+    if (bvh.tris) (void)hipFree(bvh.tris);
+    bvh = LbvhResult{};
+    for (int k = 0; k < 2; k++) { st_rayO[k].release(); st_rayD[k].release(); st_att[k].release(); st_pid[k].release(); }
+    seg_active[0].release(); seg_active[1].release(); seg_shadow.release(); wave_stats.release(); chunk_table[0].release(); chunk_table[1].release(); gmon_buckets_d.release(); render_target.release();
+    hit.release(); sq_o.release(); sq_d.release(); sq_c.release(); Lbuf.release(); acc_own.release(); spill.release();
+    acc = nullptr;
+    started = false;
+  }
+  void drop_timed() {
+    for (auto& t : timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    timed.clear();
+  }
+};
+
+
+// ---- the single-device driver (renderer.hip); the extern "C" entry points (multi_device.hip) dispatch here or to the group ----
+int dev_create(const pt_create_info* info, int device_ordinal, pt_renderer** out);
+void dev_destroy(pt_renderer* r);
+int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_render_params* p);
+int dev_render_step(pt_renderer* r, uint32_t max_spp);
+int dev_wait(pt_renderer* r);
+int dev_status(const pt_renderer* r);
+int dev_progress(const pt_renderer* r, uint64_t* accumulated, uint64_t* total);
+uint64_t dev_render_time_ms(const pt_renderer* r);
+int dev_read_accumulator(pt_renderer* r, float* rgba_out);
+int dev_set_post_options(pt_renderer* r, const pt_post_options* o);
+int dev_set_tonemap_options(pt_renderer* r, const pt_tonemap_options* o);
+int dev_read_render_target(pt_renderer* r, uint8_t* rgba8_out);
+int dev_postprocess_to_host(pt_renderer* r, const vec4* acc_device, uint8_t* rgba8_out);  // the tail of read_render_target on a given image
+int dev_set_gmon_options(pt_renderer* r, const pt_gmon_options* o);
+int dev_read_gmon_bucket(pt_renderer* r, uint32_t bucket, float* rgba_out);
+void* dev_accumulator_device_ptr(pt_renderer* r);
+int dev_get_constants(const pt_renderer* r, pt_constants* out);
+int dev_get_lights(const pt_renderer* r, pt_area_light* out, uint32_t capacity, uint32_t* count);
+int dev_get_env_alias(const pt_renderer* r, pt_alias_entry* out, uint64_t capacity, uint64_t* count);
+int dev_trace_primary(pt_renderer* r, uint32_t sample_idx, pt_hit_record* out);
+int dev_debug_sample(pt_renderer* r, uint32_t sample_idx, float* radiance_out, int32_t* hits_out);
+int dev_measure_traversal(pt_renderer* r, uint32_t sample_idx);
+int dev_set_profiling(pt_renderer* r, int enabled);
+int dev_get_stats(pt_renderer* r, pt_stats* out);

@@ -30,12 +30,17 @@ class Renderer:
     Integrator_Simple, Integrator_MIS = abi.INTEGRATOR_SIMPLE, abi.INTEGRATOR_MIS
     Status_Blocked, Status_Ready, Status_Busy, Status_Done = 0, 1, 4, 8
 
-    def __init__(self, device=0, lut_path=None):
-        """Renderer(device, queue, store) (renderer_pt.cpp:18-60). Raises if the HIP library or a GPU is missing."""
+    def __init__(self, device=0, lut_path=None, devices=None):
+        """Renderer(device, queue, store) (renderer_pt.cpp:18-60). Raises if the HIP library or a GPU is missing.
+        `devices` = a list of HIP device ordinals: a device group that shards every render's samples (include/ptamd.h)."""
         self._lib = abi.load_library()
         info = abi.CreateInfo()
         info.abi_version = abi.PT_ABI_VERSION
         info.device_ordinal = device
+        if devices is not None:
+            self._devices = (C.c_int32 * len(devices))(*devices)
+            info.device_ordinals = self._devices
+            info.device_count = len(devices)
         self._lut = open(lut_path or abi.LUT_PATH, "rb").read()
         self._lut_buf = C.create_string_buffer(self._lut, len(self._lut))
         info.lut_blob = C.addressof(self._lut_buf)

@@ -1,0 +1,161 @@
+"""The device group behind the C ABI (include/ptamd.h pt_create_info.device_ordinals, platinum_amd/csrc/multi_device.hip;
+SURVEY §8e): samples dealt to the members in contiguous ranges, ONE reduction of the float accumulator at the end, GMoN
+buckets mapped to devices and resolved on the first one.
+
+CPU: the partition arithmetic (pt_group_partition).  GPU (one device is enough: a device listed twice = two logical shards
+with their own host threads, streams, scene copies and accumulators, merged by the same code path minus RCCL; with two
+or more devices present the RCCL all-reduce itself is exercised)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from platinum_amd import Renderer, abi, scenes
+
+
+def _partition(spp, members, flags=abi.FLAG_MULTISCATTER_GGX, buckets=1):
+    lib = abi.load_library()
+    first, count = (C.c_uint64 * members)(), (C.c_uint64 * members)()
+    b0, b1 = (C.c_uint32 * members)(), (C.c_uint32 * members)()
+    abi.check(lib, lib.pt_group_partition(spp, members, flags, buckets, first, count, b0, b1))
+    return list(first), list(count), list(b0), list(b1)
+
+
+def test_partition_is_a_contiguous_cover_of_the_sample_range():
+    for spp, n in [(1024, 8), (128, 2), (5, 2), (7, 3), (3, 8), (1, 4), (1000, 7)]:
+        first, count, _, _ = _partition(spp, n)
+        assert first[0] == 0 and sum(count) == spp
+        assert all(first[g + 1] == first[g] + count[g] for g in range(n - 1))
+        assert max(count) - min(count) <= 1
+    # BASELINE.json configs[3]: 1024 spp = 128 spp x 8 seeds
+    first, count, _, _ = _partition(1024, 8)
+    assert count == [128] * 8 and first == [128 * g for g in range(8)]
+
+
+def test_partition_follows_gmon_bucket_boundaries():
+    """bucket b = samples [b * ceil(spp / B), ...) (renderer_pt.cpp:124-126): every bucket lives on exactly one member."""
+    flags = abi.FLAG_MULTISCATTER_GGX | abi.FLAG_GMON
+    for spp, buckets, n in [(128, 15, 8), (30, 15, 2), (17, 5, 3), (100, 32, 8), (10, 3, 8)]:
+        first, count, b0, b1 = _partition(spp, n, flags, buckets)
+        spb = -(-spp // buckets)
+        assert b0[0] == 0 and b1[-1] == buckets and all(b1[g] == b0[g + 1] for g in range(n - 1))
+        assert sum(count) == spp
+        for g in range(n):
+            assert first[g] == min(b0[g] * spb, spp) and first[g] + count[g] == min(b1[g] * spb, spp)
+    lib = abi.load_library()
+    assert lib.pt_group_partition(16, 2, flags, 33, (C.c_uint64 * 2)(), (C.c_uint64 * 2)(), None, None) != 0
+
+
+W, H, B = 96, 64, 5
+
+
+def _render(devices, scene, spp, **kw):
+    r = Renderer(devices=devices) if devices is not None else Renderer(device=0)
+    try:
+        r.startRender(scene, (W, H), spp, max_bounces=B, **kw)
+        assert r.status() == Renderer.Status_Busy
+        r.render(0)
+        r.wait()
+        assert r.status() == (Renderer.Status_Ready | Renderer.Status_Done)
+        assert r.renderProgress() == (spp, spp)
+        return r.readbackAccumulator(), r.stats(), r
+    except Exception:
+        r.close()
+        raise
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spp,shards", [(8, 2), (5, 2), (9, 3), (2, 4)])
+def test_logical_shards_equal_the_single_render(spp, shards):
+    """Two (three, four) members on device 0 against one renderer tracing the union of their sample ranges: the same image
+    up to fp32 summation order (<= 1e-6 relative), alpha 1, ray counters add up."""
+    sc = scenes.cornell_sphere_scene()
+    ref, st1, r1 = _render(None, sc, spp, samples_in_flight=3)
+    r1.close()
+    got, stn, rn = _render([0] * shards, sc, spp, samples_in_flight=3)
+    try:
+        assert np.array_equal(got[..., 3], np.ones((H, W), np.float32))
+        np.testing.assert_allclose(got[..., :3], ref[..., :3], rtol=2e-6, atol=1e-6)
+        assert (stn.closest_rays, stn.shadow_rays, stn.shaded_hits, stn.paths) == (st1.closest_rays, st1.shadow_rays, st1.shaded_hits, st1.paths)
+        # progressive use: a second render on the same group, read in the middle
+        rn.startRender(sc, (W, H), spp, max_bounces=B, first_sample=3)
+        rn.render(shards)             # one sample per member
+        mid = rn.readbackAccumulator()
+        assert np.isfinite(mid).all() and mid[..., :3].max() > 0
+        rn.render(0)
+        full = rn.readbackAccumulator()
+    finally:
+        rn.close()
+    r1 = Renderer(device=0)
+    try:
+        r1.startRender(sc, (W, H), spp, max_bounces=B, first_sample=3)
+        r1.render(0)
+        np.testing.assert_allclose(full[..., :3], r1.readbackAccumulator()[..., :3], rtol=2e-6, atol=1e-6)
+    finally:
+        r1.close()
+
+
+@pytest.mark.gpu
+def test_group_writes_the_merged_image_into_an_external_accumulator():
+    torch = pytest.importorskip("torch")
+    sc = scenes.cornell_scene("bench")
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    r = Renderer(devices=[0, 0])
+    try:
+        r.startRender(sc, (W, H), 6, max_bounces=B, external_accumulator=acc.data_ptr())
+        r.render(0)
+        r.wait()
+        assert r.accumulatorDevicePtr() == acc.data_ptr()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(acc.cpu().numpy(), r.readbackAccumulator())
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spp,buckets,shards", [(30, 15, 2), (17, 5, 3), (12, 4, 8)])
+def test_gmon_buckets_map_to_members_and_resolve_bit_identically(spp, buckets, shards):
+    """SURVEY §8e last sentence: buckets -> devices, bucket means gathered, k_gmon on the first device: every bucket image and
+    the resolved accumulator are BIT-identical to the single-device render."""
+    sc = scenes.cornell_sphere_scene()
+    flags = abi.FLAG_MULTISCATTER_GGX | abi.FLAG_GMON
+    ref, _, r1 = _render(None, sc, spp, gmonBuckets=buckets, flags=flags, samples_in_flight=4)
+    ref_b = [r1.readGmonBucket(b) for b in range(buckets)]
+    r1.close()
+    got, _, rn = _render([0] * shards, sc, spp, gmonBuckets=buckets, flags=flags, samples_in_flight=4)
+    try:
+        for b in range(buckets):
+            assert rn.readGmonBucket(b).tobytes() == ref_b[b].tobytes(), b
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+        img = rn.readbackRenderTarget()
+        assert img.shape == (H, W, 4) and img[..., 3].min() == 255
+    finally:
+        rn.close()
+
+
+@pytest.mark.gpu
+def test_group_argument_errors():
+    lib = abi.load_library()
+    info = abi.CreateInfo()
+    info.abi_version = abi.PT_ABI_VERSION
+    info.lut_path = abi.LUT_PATH.encode()
+    info.device_count = 2
+    h = C.c_void_p()
+    assert lib.pt_create(C.byref(info), C.byref(h)) != 0          # count without a list
+    devs = (C.c_int32 * 2)(0, 9999)
+    info.device_ordinals = devs
+    assert lib.pt_create(C.byref(info), C.byref(h)) != 0 and b"ordinal" in lib.pt_last_error()
+
+
+@pytest.mark.gpu
+def test_two_physical_devices_rccl_all_reduce():
+    """The RCCL path proper (needs >= 2 GPUs; the 1-GPU box skips it)."""
+    torch = pytest.importorskip("torch")
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU: the all-reduce over distinct devices cannot run here")
+    sc = scenes.cornell_sphere_scene()
+    ref, _, r1 = _render(None, sc, 8)
+    r1.close()
+    got, _, rn = _render([0, 1], sc, 8)
+    rn.close()
+    np.testing.assert_allclose(got[..., :3], ref[..., :3], rtol=2e-6, atol=1e-6)
