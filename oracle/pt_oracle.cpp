@@ -1650,6 +1650,205 @@ void orc_sample_cosine_hemisphere(float u0, float u1, float out[3]) {
   float3 w = sampleCosineHemisphere({u0, u1}); out[0] = w.x; out[1] = w.y; out[2] = w.z;
 }
 void orc_sample_tri_uniform(float u0, float u1, float out[2]) { float2 b = sampleTriUniform({u0, u1}); out[0] = b.x; out[1] = b.y; }
+// ---- LUT generator restatement (pins A7-A9 against reference-held data) -------------------------------------------------
+// The eight energy tables the renderer loads (resource/lut/*.exr -> platinum_amd/data/ggx_luts.bin) are Monte-Carlo integrals
+// of the reference's own lobes, produced by its tool /root/reference/src/frontend/windows/tools/shaders/ms_lut_gen.metal:
+//   :337-389 E            generateDirectionalAlbedoLookup          (cosTheta x, roughness y; the 0.961 "funny hack")
+//   :395-441 E_avg        generateHemisphericalAlbedoLookup
+//   :447-505 E_ms         generateMultiscatterDirectionalAlbedoLookup   (samples E and E_avg)
+//   :511-571 E_ms_avg     generateMultiscatterHemisphericalAlbedoLookup
+//   :576-650 E_trans_in / out   generateTransparentDirectionalAlbedoLookup
+//   :656-743 E_trans_in_avg / out_avg   generateTransparentHemisphericalAlbedoLookup  (r.w == r.z: the same Halton dimension twice)
+// Recomputing a texel with the ORACLE's fresnel / avgDielectricFresnelFit / sampleVmdf / refract / LUT sampling and the tool's
+// integrand, and finding the value the reference committed, pins those functions against data the reference holds.
+// The tool's GGX differs from the renderer's in two places, both restated here: lambda() is the textbook
+// alpha^2 tan^2(theta) (:203-217; the renderer's isotropic lambda has no sin^2, bsdf.metal:173-182) and mdf() is written with
+// tan^2 (:121-141).  `lambda_mode` bit 0 swaps in the renderer's lambda (to show that the tables tell the two apart), bit 1
+// drops the multiscatter term of the E_ms integrand, bit 2 the 0.961 corner factor of E (see the FINDINGs below).
+namespace lutgen {
+struct GGXGen {  // ms_lut_gen.metal:110-218
+  float ax, ay;
+  int lambda_mode;
+  GGXGen(float roughness, int mode) : lambda_mode(mode) { ax = ay = roughness * roughness; }
+  float lambda(float3 w) const {
+    if (lambda_mode == 1) return GGX(sqrtf(ax)).lambda(w);  // (never used for the pin itself)
+    const float cos2Theta = w.z * w.z;
+    const float sin2Theta = 1.0f - cos2Theta;
+    const float tan2Theta = sin2Theta / cos2Theta;
+    const float alpha2 = ax * ax;  // isotropic tables only
+    return (sqrtf(1.0f + alpha2 * tan2Theta) - 1.0f) * 0.5f;
+  }
+  float mdf(float3 w) const {
+    const float cos2Theta = w.z * w.z;
+    const float sin2Theta = fmaxf(0.0f, 1.0f - cos2Theta);
+    const float tan2Theta = sin2Theta / cos2Theta;
+    const float cos4Theta = cos2Theta * cos2Theta;
+    float k = tan2Theta;
+    k /= (ax * ax);
+    k = (1.0f + k) * (1.0f + k);
+    return 1.0f / (PI_F * ax * ay * cos4Theta * k);
+  }
+  float g1(float3 w) const { return 1.0f / (1.0f + lambda(w)); }
+  float g(float3 wo, float3 wi) const { return 1.0f / (1.0f + lambda(wo) + lambda(wi)); }
+  float vmdf(float3 w, float3 wm) const { return g1(w) / fabsf(w.z) * mdf(wm) * fabsf(dot(w, wm)); }
+  float3 sampleVmdf(float3 w, float2 u) const { GGX r(0.0f); r.ax = ax; r.ay = ay; return r.sampleVmdf(w, u); }  // identical text (:166-181)
+  float singleScatterBRDF(float3 wo, float3 wi, float3 wm) const { return mdf(wm) * g(wo, wi) / (4 * fabsf(wo.z) * fabsf(wi.z)); }
+  float pdf(float3 wo, float3 wm) const { return vmdf(wo, wm) / (4.0f * fabsf(dot(wo, wm))); }
+};
+struct GenSample { float3 wi; float f, pdf; };
+
+GenSample sampleSingleScatterGGX(float3 wo, const GGXGen& ggx, float2 r) {  // :232-247
+  const float3 wm = ggx.sampleVmdf(wo, r);
+  const float3 wi = reflect(-wo, wm);
+  if (wm.z <= 0.0f || wo.z * wi.z < 0.0f) return {wi, 0.0f, 1.0f};
+  return {wi, ggx.singleScatterBRDF(wo, wi, wm), ggx.pdf(wo, wm)};
+}
+GenSample sampleMultiscatterDielectricGGX(float3 wo, float ior, float roughness, const GGXGen& ggx, float2 r, const LutSet& luts,
+                                          bool with_ms_term) {  // :252-282
+  const float3 wm = ggx.sampleVmdf(wo, r);
+  const float3 wi = reflect(-wo, wm);
+  if (wo.z * wi.z < 0.0f) return {wi, 0.0f, 1.0f};
+  const float cosTheta_o = fabsf(wo.z), cosTheta_i = fabsf(wi.z);
+  const float brdf_ss = ggx.mdf(wm) * ggx.g(wo, wi) / (4 * cosTheta_o * cosTheta_i);
+  const float fresnel_ss = fresnel(fabsf(dot(wo, wm)), ior);
+  const float E_wo = lut2(luts.E, wo.z, roughness);
+  const float E_wi = lut2(luts.E, wi.z, roughness);
+  const float E_avg = lut1(luts.Eavg, roughness);
+  const float F_avg = avgDielectricFresnelFit(ior);
+  const float brdf_ms = (1.0f - E_wo) * (1.0f - E_wi) / (PI_F * (1.0f - E_avg));
+  const float fresnel_ms = F_avg * F_avg * E_avg / (1.0f - F_avg * (1.0f - E_avg));
+  // FINDING (tools/lut_pin.py): the committed ggx_ms_E_*.exr / ggx_ms_E_avg.exr equal this integral WITHOUT the
+  // fresnel_ms * brdf_ms term to ~1e-4 at every texel (and differ from the integral as written by up to 0.44 at high ior and
+  // roughness): the reference's data files hold the single-scatter, Fresnel-weighted albedo.  with_ms_term = false reproduces them.
+  const float f = with_ms_term ? fresnel_ss * brdf_ss + fresnel_ms * brdf_ms : fresnel_ss * brdf_ss;
+  return {wi, f, ggx.vmdf(wo, wm) / (4.0f * fabsf(dot(wo, wm)))};
+}
+GenSample sampleTransparentDielectricGGX(float3 wo, const GGXGen& ggx, float ior, float3 r) {  // :287-331 (thin = false)
+  const float3 wm = ggx.sampleVmdf(wo, {r.x, r.y});
+  const float fresnel_ss = fresnel(fabsf(dot(wo, wm)), ior);
+  float3 wi;
+  if (r.z < fresnel_ss) {
+    wi = reflect(-wo, wm);
+    if (wo.z * wi.z < 0.0f) return {wi, 0.0f, 1.0f};
+  } else {
+    wi = refract(-wo, wm * sign(dot(wo, wm)), 1.0f / ior);
+    if (wo.z * wi.z >= 0.0f) return {wi, 0.0f, 1.0f};
+  }
+  const bool isReflection = wo.z * wi.z > 0.0f;
+  float bsdf, pdf;
+  if (isReflection) {
+    bsdf = ggx.singleScatterBRDF(wo, wi, wm);
+    pdf = ggx.pdf(wo, wm);
+  } else {
+    float denom = dot(wi, wm) * ior + dot(wo, wm);
+    denom *= denom;
+    const float dwm_dwi = fabsf(dot(wi, wm)) / denom;
+    bsdf = ggx.mdf(wm) * ggx.g(wo, wi) * fabsf(dot(wi, wm) * dot(wo, wm) / (wi.z * wo.z * denom));
+    pdf = ggx.vmdf(wo, wm) * dwm_dwi;
+  }
+  const float k = isReflection ? fresnel_ss : 1.0f - fresnel_ss;
+  return {wi, k * bsdf, k * pdf};
+}
+}  // namespace lutgen
+
+// The generator's integral for table `which` (0 E, 1 E_avg, 2 E_ms, 3 E_ms_avg, 4 E_trans_in, 5 E_trans_out, 6 E_trans_in_avg,
+// 7 E_trans_out_avg) at explicit parameters, `nsamples` Halton samples from index `offset` (the tool uses a random per-texel
+// offset, ms_lut_gen.cpp:235-237).  cosTheta is ignored by the hemispherical tables (they draw it from dimension 2).
+double orc_lut_regen(const orc_scene* sc, int which, float cosTheta, float roughness, float ior, uint32_t nsamples, uint32_t offset,
+                     int lambda_mode) {
+  using namespace lutgen;
+  auto H = [&](uint32_t i, uint32_t d) {  // the tool's own halton (no clamp): ms_lut_gen.metal:30-45
+    uint32_t b = g_primes.p[d];
+    float f = 1.0f, invB = 1.0f / (float)b, r = 0;
+    while (i > 0) { f = f * invB; r = r + f * (float)(i % b); i = i / b; }
+    return r;
+  };
+  const GGXGen ggx(roughness, lambda_mode & 1);
+  const bool with_ms = (lambda_mode & 2) == 0;    // mode bit 0: the renderer's lambda; bit 1: E_ms tables without the multiscatter term
+  const bool with_hack = (lambda_mode & 4) == 0;  // bit 2: E without the 0.961 corner factor
+  double sum = 0.0;
+  for (uint32_t s = 0; s < nsamples; s++) {
+    const uint32_t idx = offset + s;
+    const float r0 = H(idx, 0), r1 = H(idx, 1), r2 = H(idx, 2);
+    float v = 0.0f;
+    switch (which) {
+      case 0: {
+        const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+        const GenSample sm = sampleSingleScatterGGX(f3(sinTheta, 0.0f, cosTheta), ggx, {r0, r1});
+        v = sm.f * fabsf(sm.wi.z) / sm.pdf;
+        // "Funny hack" (:371-374).  FINDING: the committed ggx_E.exr does not carry it (its 4 x 8 corner texels are ~1.0 where
+        // the hack gives 0.961): mode bit 2 leaves it out
+        if (with_hack && roughness < 2.0f / 32.0f && cosTheta < 1.0f / 32.0f) v *= 0.961f;
+        break;
+      }
+      case 1: {
+        const float ct = r2, sinTheta = sqrtf(1.0f - ct * ct);
+        const float3 wo = f3(sinTheta, 0.0f, ct);
+        const GenSample sm = sampleSingleScatterGGX(wo, ggx, {r0, r1});
+        v = 2.0f * sm.f * fabsf(sm.wi.z) * wo.z / sm.pdf;
+        break;
+      }
+      case 2: {
+        const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+        const GenSample sm = sampleMultiscatterDielectricGGX(f3(sinTheta, 0.0f, cosTheta), ior, roughness, ggx, {r0, r1}, sc->luts, with_ms);
+        v = sm.f * fabsf(sm.wi.z) / sm.pdf;
+        break;
+      }
+      case 3: {
+        const float ct = r2, sinTheta = sqrtf(1.0f - ct * ct);
+        const float3 wo = f3(sinTheta, 0.0f, ct);
+        const GenSample sm = sampleMultiscatterDielectricGGX(wo, ior, roughness, ggx, {r0, r1}, sc->luts, with_ms);
+        v = 2.0f * sm.f * fabsf(sm.wi.z) * fabsf(wo.z) / sm.pdf;
+        break;
+      }
+      case 4: case 5: {
+        const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+        const float3 wo = f3(sinTheta, 0.0f, cosTheta * (which == 5 ? -1.0f : 1.0f));
+        const GenSample sm = sampleTransparentDielectricGGX(wo, ggx, ior, f3(r0, r1, r2));
+        v = sm.f * fabsf(sm.wi.z) / sm.pdf;
+        break;
+      }
+      default: {
+        const float ct = r2 * 2.0f - 1.0f;  // r.w: halton dimension 2 again (:709-712)
+        const float sinTheta = sqrtf(1.0f - ct * ct);
+        const GenSample sm = sampleTransparentDielectricGGX(f3(sinTheta, 0.0f, ct), ggx, ior, f3(r0, r1, r2));
+        v = sm.f * fabsf(sm.wi.z) / sm.pdf;
+        break;
+      }
+    }
+    if (v == v) sum += (double)v;  // (a 0/0 sample at a grazing texel contributes nothing)
+  }
+  return sum / (double)nsamples;
+}
+
+// One texel of table `which`, parameters from the texel centre exactly as the tool computes them (:351-352, :411, :465-472,
+// :527-533, :594-601, :674-680)
+double orc_lut_regen_texel(const orc_scene* sc, int which, int x, int y, int z, uint32_t nsamples, uint32_t seed, int lambda_mode) {
+  const Lut* ls[8] = {&sc->luts.E, &sc->luts.Eavg, &sc->luts.EMs, &sc->luts.EavgMs, &sc->luts.ETransIn, &sc->luts.ETransOut,
+                      &sc->luts.EavgTransIn, &sc->luts.EavgTransOut};
+  const float size = (float)ls[which]->w;
+  const uint32_t offset = pcg4d({(uint32_t)x, (uint32_t)y, (uint32_t)z + 977u * (uint32_t)which, seed}).x % (1024u * 1024u);
+  float cosTheta = 0.0f, roughness = 0.0f, iorParam = 0.0f;
+  bool out = false;
+  switch (which) {
+    case 0: roughness = ((float)y + 0.5f) / size; cosTheta = ((float)x + 0.5f) / size; break;
+    case 1: roughness = ((float)x + 0.5f) / size; break;
+    case 2: case 4: case 5:
+      iorParam = ((float)z + 0.5f) / size; roughness = ((float)y + 0.5f) / size; cosTheta = ((float)x + 0.5f) / size; out = which == 5; break;
+    default: roughness = ((float)y + 0.5f) / size; iorParam = ((float)x + 0.5f) / size; out = which == 7; break;
+  }
+  const float ior = out ? 1.0f - iorParam : 1.0f / (1.0f - iorParam);
+  return orc_lut_regen(sc, which, cosTheta, roughness, ior, nsamples, offset, lambda_mode);
+}
+
+// the committed value of that texel
+float orc_lut_texel(const orc_scene* sc, int which, int x, int y, int z) {
+  const Lut* ls[8] = {&sc->luts.E, &sc->luts.Eavg, &sc->luts.EMs, &sc->luts.EavgMs, &sc->luts.ETransIn, &sc->luts.ETransOut,
+                      &sc->luts.EavgTransIn, &sc->luts.EavgTransOut};
+  const Lut& l = *ls[which];
+  return l.d[((size_t)z * l.h + y) * l.w + x];
+}
+
 float orc_lut_sample(const orc_scene* sc, int which, float cx, float cy, float cz) {
   const Lut* ls[8] = {&sc->luts.E, &sc->luts.Eavg, &sc->luts.EMs, &sc->luts.EavgMs, &sc->luts.ETransIn, &sc->luts.ETransOut,
                       &sc->luts.EavgTransIn, &sc->luts.EavgTransOut};

@@ -51,6 +51,11 @@ void orc_tex_sample(const orc_scene* sc, int texture, float u, float v, float ou
 void orc_ray_dir_to_uv(const float dir[3], float out[2]);
 void orc_uv_to_ray_dir(const float uv[2], float out[3]);
 float orc_lut_sample(const orc_scene* sc, int which, float cx, float cy, float cz);
+// LUT generator restatement (ms_lut_gen.metal:337-743): one texel of table `which` re-integrated with the oracle's BSDF pieces
+double orc_lut_regen(const orc_scene* sc, int which, float cosTheta, float roughness, float ior, uint32_t nsamples, uint32_t offset,
+                     int lambda_mode);
+double orc_lut_regen_texel(const orc_scene* sc, int which, int x, int y, int z, uint32_t nsamples, uint32_t seed, int lambda_mode);
+float orc_lut_texel(const orc_scene* sc, int which, int x, int y, int z);
 void orc_bsdf_sample(const orc_scene* sc, const pt_material_gpu* mat, const float wo[3], const float r[4], const float rc[2],
                      float out_sample[11]);
 void orc_bsdf_eval(const orc_scene* sc, const pt_material_gpu* mat, const float wo[3], const float wi[3], float out_eval[4]);

@@ -77,6 +77,12 @@ def lib():
     L.orc_sample_tri_uniform.argtypes = [C.c_float, C.c_float, C.c_float * 2]
     L.orc_lut_sample.restype = C.c_float
     L.orc_lut_sample.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float]
+    L.orc_lut_regen.restype = C.c_double
+    L.orc_lut_regen.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_int]
+    L.orc_lut_regen_texel.restype = C.c_double
+    L.orc_lut_regen_texel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int]
+    L.orc_lut_texel.restype = C.c_float
+    L.orc_lut_texel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.orc_bsdf_sample.argtypes = [C.c_void_p, C.POINTER(abi.MaterialGPU), C.c_float * 3, C.c_float * 4, C.c_float * 2, C.c_float * 11]
     L.orc_bsdf_eval.argtypes = [C.c_void_p, C.POINTER(abi.MaterialGPU), C.c_float * 3, C.c_float * 3, C.c_float * 4]
     _lib = L
