@@ -46,7 +46,7 @@ WORKLOADS = {
     "c1": "C1 Cornell box 512x512",
     "c2": "C2 Cornell box + GGX dielectric sphere (6144 tris), 1920x1080",
     "c3": "C3 1.04M-triangle instanced sphere field, 1920x1080",
-    "c5": "C5 procedural Sponza-class atrium (258k tris, textures, cut-outs, 4096x2048 environment), 3840x2160",
+    "c5": "C5 Sponza-class atrium (258k tris, JPEG/PNG textures, cut-outs, 4096x2048 EXR environment) imported from .glb + .exr, 3840x2160",
 }
 
 
@@ -79,6 +79,7 @@ def parse_args(argv=None):
     ap.add_argument("--pmc-pass", action="store_true",
                     help="under rocprofv3 --pmc: only full-size batches (no warm-up, no instrumented sample, no CPU leg, no event timing)")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the second (event-timed) pass")
+    ap.add_argument("--c5-in-memory", action="store_true", help="c5: the procedural snapshot directly instead of the .glb + .exr ingestion path")
     return ap.parse_args(argv)
 
 
@@ -200,7 +201,14 @@ def main():
     factory, W, H, full_spp, B = scenes.CONFIGS[args.workload]
     S, K = args.spp_per_step, args.steps
     Wu = 0 if args.pmc_pass else args.warmup
-    scene = factory()
+    if args.workload == "c5" and not args.c5_in_memory:
+        # the C5-class scene enters as FILES through scene ingestion (pt_scene_import_gltf + pt_scene_load_environment): a .glb with
+        # JPEG / PNG textures and a 4096x2048 OpenEXR environment, written once by tools/export_gltf.py (no asset exists offline)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import export_gltf
+        scene = export_gltf.atrium_through_ingestion(os.path.join(os.environ.get("TMPDIR", "/tmp"), "ptamd_c5_cache"))
+    else:
+        scene = factory()
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     ndev = args.gpus if inproc else 1       # devices driven by THIS process

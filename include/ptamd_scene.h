@@ -64,6 +64,12 @@ int pt_scene_build_snapshot(pt_scene* s, uint64_t camera_node, const pt_scene_sn
 int pt_generate_tangents(const pt_float3* positions, pt_vertex_data* vertex_data, uint32_t vertex_count, const uint32_t* indices,
                          uint32_t triangle_count);
 
+/* An 8-bit image file in memory -> RGBA8, as stbi_load_from_memory(data, len, &w, &h, nullptr, 4) gives the texture loader
+ * (loaders/texture.cpp:111-119): PNG (all colour types, 1-16 bit, tRNS; no Adam7) and JPEG (baseline + progressive, 1 / 3 / 4
+ * components, any sampling factors, restart intervals; stb_image's IDCT / upsampling / colour arithmetic, bit-identical to it).
+ * Writes width * height * 4 bytes when `rgba_out` is non-NULL and `capacity` suffices; always returns the size. */
+int pt_decode_image_rgba8(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, uint8_t* rgba_out, uint64_t capacity);
+
 const char* pt_scene_last_error(void);
 
 #ifdef __cplusplus

@@ -4,7 +4,7 @@
 // Host-only C++17.  Third-party pieces of the reference that are restated from their published behaviour:
 //   fastgltf (deps/fastgltf, headers only in the tree): accessor iteration with component conversion, material defaults
 //     (types.hpp:1873-2014), decomposeTransformMatrix (math.hpp:854-891)
-//   stb_image (deps/stb_image): PNG -> 8-bit RGBA.  JPEG is NOT decoded here: such an image is a loud PT error.
+//   stb_image (deps/stb_image): PNG -> 8-bit RGBA here, JPEG -> 8-bit RGBA in scene_jpeg.cpp.
 //   mikktspace.c (deps/mikkt): the tangent-space algorithm, restated for triangle lists; pinned by tests against the
 //     reference's own mikktspace.c compiled into oracle/_ref (tests/test_scene_ingestion.py).
 #include "scene_io.h"
@@ -34,7 +34,6 @@ static uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t
 std::vector<uint8_t> decode_png_rgba8(const uint8_t* data, size_t len, uint32_t* w_out, uint32_t* h_out) {
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
   if (len < 8 || memcmp(data, sig, 8)) {
-    if (len >= 3 && data[0] == 0xFF && data[1] == 0xD8) fail("image: JPEG is not supported by this importer (PNG only)");
     fail("image: not a PNG");
   }
   uint32_t w = 0, h = 0;
@@ -568,7 +567,8 @@ struct Importer {
       v = {(const uint8_t*)storage.data(), storage.size()};
     } else fail("gltf: image has neither bufferView nor uri");
     uint32_t w = 0, h = 0;
-    const std::vector<uint8_t> rgba = decode_png_rgba8(v.p, v.len, &w, &h);
+    // stbi_load_from_memory(data, len, &w, &h, nullptr, 4) (texture.cpp:111-119): the format is sniffed from the bytes
+    const std::vector<uint8_t> rgba = is_jpeg(v.p, v.len) ? decode_jpeg_rgba8(v.p, v.len, &w, &h) : decode_png_rgba8(v.p, v.len, &w, &h);
     Asset a;
     a.type = Asset::TEXTURE;
     a.tex.name = sname(tex);

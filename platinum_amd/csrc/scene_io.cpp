@@ -784,4 +784,18 @@ int pt_generate_tangents(const pt_float3* positions, pt_vertex_data* vdata, uint
   });
 }
 
+int pt_decode_image_rgba8(const uint8_t* data, uint64_t len, uint32_t* width, uint32_t* height, uint8_t* rgba_out, uint64_t capacity) {
+  if (!data || !width || !height) { ptio::g_error = "null argument"; return PT_ERR_INVALID_ARGUMENT; }
+  return guarded([&] {
+    uint32_t w = 0, h = 0;
+    const std::vector<uint8_t> px = ptio::is_jpeg(data, (size_t)len) ? ptio::decode_jpeg_rgba8(data, (size_t)len, &w, &h)
+                                                                      : ptio::decode_png_rgba8(data, (size_t)len, &w, &h);
+    *width = w; *height = h;
+    if (rgba_out) {
+      if (capacity < px.size()) throw std::runtime_error("image: output buffer too small");
+      memcpy(rgba_out, px.data(), px.size());
+    }
+  });
+}
+
 }  // extern "C"

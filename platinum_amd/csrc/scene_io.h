@@ -120,5 +120,7 @@ void generate_tangents(const pt_float3* positions, pt_vertex_data* vdata, uint32
 std::vector<float> read_exr_rgba(const std::string& path, uint32_t* w, uint32_t* h);            // scene_image.cpp
 std::vector<float> read_radiance_hdr_rgba(const std::string& path, uint32_t* w, uint32_t* h);   // scene_image.cpp
 std::vector<uint8_t> decode_png_rgba8(const uint8_t* data, size_t len, uint32_t* w, uint32_t* h);  // scene_gltf.cpp
+bool is_jpeg(const uint8_t* data, size_t len);                                                      // scene_jpeg.cpp
+std::vector<uint8_t> decode_jpeg_rgba8(const uint8_t* data, size_t len, uint32_t* w, uint32_t* h); // scene_jpeg.cpp
 
 }  // namespace ptio

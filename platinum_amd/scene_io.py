@@ -30,6 +30,7 @@ SCENE_SYMBOLS = [
     ("pt_scene_add_camera", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_uint64)]),
     ("pt_scene_build_snapshot", C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.POINTER(abi.SceneSnapshot))]),
     ("pt_generate_tangents", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    ("pt_decode_image_rgba8", C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64]),
     ("pt_scene_last_error", C.c_char_p, []),
 ]
 
@@ -145,3 +146,12 @@ def generate_tangents(positions, vertex_data, indices):
     assert vertex_data.dtype == np.float32 and vertex_data.flags["C_CONTIGUOUS"] and vertex_data.shape[1] == 12
     _check(_lib().pt_generate_tangents(pos.ctypes.data, vertex_data.ctypes.data, len(pos), idx.ctypes.data, len(idx) // 3))
     return vertex_data
+
+
+def decode_image_rgba8(data):
+    """bytes of a PNG / JPEG file -> (H, W, 4) uint8, as stbi_load_from_memory(..., 4) (loaders/texture.cpp:111-119)."""
+    w, h = C.c_uint32(), C.c_uint32()
+    _check(_lib().pt_decode_image_rgba8(data, len(data), C.byref(w), C.byref(h), None, 0))
+    out = np.empty((h.value, w.value, 4), dtype=np.uint8)
+    _check(_lib().pt_decode_image_rgba8(data, len(data), C.byref(w), C.byref(h), out.ctypes.data, out.nbytes))
+    return out

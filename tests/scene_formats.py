@@ -11,6 +11,7 @@ import ctypes as C
 import json
 import os
 import struct
+import subprocess
 import zlib
 
 import numpy as np
@@ -416,3 +417,16 @@ def tinyexr_reference_rgba(exr_path, tmp_dir):
     raw = open(out, "rb").read()
     w, h = struct.unpack_from("<ii", raw, 0)
     return np.frombuffer(raw, dtype=np.float32, offset=8).reshape(h, w, 4)
+
+
+def stbi_available():
+    return os.path.exists(os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "stbi2raw"))
+
+
+def stbi_reference_rgba(path):
+    """(H, W, 4) uint8 decoded by the reference's own stb_image v2.30 exactly as loaders/texture.cpp:111-119 calls it."""
+    exe = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "stbi2raw")
+    out = subprocess.run([exe, str(path)], capture_output=True, check=True).stdout
+    hdr, raw = out.split(b"\n", 1)
+    w, h = map(int, hdr.split())
+    return np.frombuffer(raw, np.uint8).reshape(h, w, 4).copy()

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     lib = abi.load_library()
     hdr = open(os.path.join(ROOT, "include", "ptamd.h")).read()
-    declared = set(re.findall(r"\b(pt_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"pt_error"}
     assert declared == {name for name, _, _ in abi.SYMBOLS}
     for name in declared:
@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     # include/ptamd_scene.h (scene ingestion)
     from platinum_amd import scene_io
     hdr2 = open(os.path.join(ROOT, "include", "ptamd_scene.h")).read()
-    declared2 = set(re.findall(r"\b(pt_[a-z_]+)\s*\(", hdr2))
+    declared2 = set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", hdr2))
     assert declared2 == {name for name, _, _ in scene_io.SCENE_SYMBOLS}
     for name in declared2:
         assert hasattr(lib, name)

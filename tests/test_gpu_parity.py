@@ -4,6 +4,8 @@ Bars: hit (instance, primitive) ids bit-exact at every bounce; radia
 configurations below (both sides implement the same deterministic fp32 contract independently), with a stated
 fallback tolerance of 1e-5 relative on per-sample radiance should a future compiler change one rounding.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -374,6 +376,32 @@ def test_atrium_c5_small_parity(gpu_renderer):
         assert np.array_equal(hg, hc) and _same_bits_or_both_nan(rg, rc)
     gpu_renderer.render(0)
     assert _same_bits_or_both_nan(gpu_renderer.readbackAccumulator(), o.render(0, 2))
+
+
+def test_atrium_c5_through_gltf_and_exr_ingestion_parity(gpu_renderer, tmp_path):
+    """the C5-class scene written as FILES (tools/export_gltf.py: .glb with JPEG + PNG textures, ZIP OpenEXR
+    environment), read by the product's loaders (pt_scene_import_gltf: JPEG decode, MikkTSpace tangents, KHR material
+    extensions; pt_scene_load_environment) and rendered on the GPU and by the oracle from that same imported snapshot."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import export_gltf
+    sc = export_gltf.atrium_through_ingestion(str(tmp_path), env_size=(256, 128), columns=6, jpeg=True)
+    c = sc.counts()
+    assert c.triangles == scenes.atrium_scene(env_size=(8, 4), columns=6).triangle_count and c.textures == 5 and c.cameras == 1
+    p = _start(gpu_renderer, sc, 192, 108, 2, 12)
+    o = oracle_lib.OracleScene(sc, p)
+    assert bytes(gpu_renderer.constants()) == bytes(o.constants())
+    assert gpu_renderer.envAlias().tobytes() == o.envAlias().tobytes()
+    for s in (0, 1):
+        rg, hg = gpu_renderer.debugSample(s)
+        rc, hc = o.debug_sample(s)
+        assert np.array_equal(hg, hc) and _same_bits_or_both_nan(rg, rc)
+    gpu_renderer.render(0)
+    acc = gpu_renderer.readbackAccumulator()
+    assert _same_bits_or_both_nan(acc, o.render(0, 2))
+    # the files describe the scene the procedural snapshot describes (JPEG quantisation and regenerated tangents aside)
+    ref = oracle_lib.OracleScene(scenes.atrium_scene(env_size=(256, 128), columns=6), p).render(0, 2)
+    assert abs(np.nanmean(acc[..., :3]) - np.nanmean(ref[..., :3])) < 0.05 * np.nanmean(ref[..., :3])
 
 
 def test_atrium_c5_full_size_properties(gpu_renderer):

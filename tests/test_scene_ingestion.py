@@ -313,7 +313,7 @@ def test_png_decoder_all_colour_types(tmp_path):
     b.image_png(b"\xff\xd8\xff\xe0" + b"\0" * 64)
     b.doc["materials"].append({"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}})
     b.write(str(tmp_path / "jpeg.glb"), glb=True)
-    with pytest.raises(abi.PtamdError, match="JPEG is not supported"):
+    with pytest.raises(abi.PtamdError, match="jpeg: "):  # a JPEG signature followed by garbage
         scene_io.SceneFile.empty().import_gltf(str(tmp_path / "jpeg.glb"))
 
 
@@ -636,3 +636,88 @@ def test_piz_huffman_malformed_tables_under_address_sanitizer(tmp_path):
     assert "AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr
     good = subprocess.run([exe, files[-1]], capture_output=True, text=True)
     assert "decoded" in good.stdout and "AddressSanitizer" not in good.stderr, good.stdout + good.stderr
+
+
+# ---- JPEG textures (stbi_load semantics, loaders/texture.cpp:101-119) -----------------------------------------------------
+def jpeg_test_image(w, h, mode):
+    """A deterministic gradient + noise image as a PIL image (PIL / libjpeg is the ENCODER here: test infrastructure)."""
+    from PIL import Image
+    rng = np.random.default_rng(w * 1000 + h)
+    y, x = np.mgrid[0:h, 0:w]
+    base = np.stack([x * 255 // max(1, w - 1), y * 255 // max(1, h - 1), (x + y) * 7 % 256], -1)
+    a = np.clip(base + rng.integers(0, 60, (h, w, 3)) - 30, 0, 255).astype(np.uint8)
+    if mode == "L":
+        return Image.fromarray(a[..., 0], "L")
+    if mode == "CMYK":
+        return Image.fromarray(np.concatenate([a, a[..., :1]], -1), "CMYK")
+    return Image.fromarray(a, "RGB")
+
+
+def jpeg_fixture_cases():
+    return [(33, 17, "RGB", dict(quality=90, subsampling=0)), (64, 48, "RGB", dict(quality=75, subsampling=1)),
+            (129, 97, "RGB", dict(quality=60, subsampling=2)), (65, 33, "RGB", dict(quality=85, subsampling=2, progressive=True)),
+            (40, 40, "RGB", dict(quality=95, subsampling=0, progressive=True, optimize=True)), (31, 29, "L", dict(quality=80)),
+            (50, 20, "L", dict(quality=70, progressive=True)), (24, 24, "CMYK", dict(quality=85)),
+            (100, 37, "RGB", dict(quality=80, subsampling=2, restart_marker_blocks=3))]
+
+
+def test_jpeg_decoder_reproduces_the_reference_stb_image_on_the_committed_files():
+    """tests/golden/jpeg_stb_fixture.npz: file bytes + the RGBA8 decoded by the reference's own stb_image (tools/make_golden.py)."""
+    g = np.load(os.path.join(G, "jpeg_stb_fixture.npz"))
+    n = len([k for k in g.files if k.startswith("jpg_")])
+    assert n == len(jpeg_fixture_cases())
+    for k in range(n):
+        got = scene_io.decode_image_rgba8(g[f"jpg_{k}"].tobytes())
+        assert got.shape == g[f"rgba_{k}"].shape and np.array_equal(got, g[f"rgba_{k}"]), k
+
+
+def test_jpeg_decoder_vs_the_reference_stb_image_over_many_variants(tmp_path):
+    """Every sampling mode x baseline / progressive (libjpeg's scripts use successive approximation) / optimised tables /
+    restart intervals x odd sizes down to 1x1: byte-identical to stb_image v2.30 compiled from the reference tree."""
+    pytest.importorskip("PIL")
+    if not sf.stbi_available():
+        pytest.skip("oracle/_ref/stbi2raw not built (reference tree absent)")
+    import io
+    n = 0
+    for (w, h) in [(1, 1), (7, 5), (16, 16), (33, 17), (129, 97), (250, 3)]:
+        for mode in ("RGB", "L", "CMYK"):
+            for kw in (dict(quality=90, subsampling=0), dict(quality=75, subsampling=1), dict(quality=60, subsampling=2),
+                       dict(quality=85, subsampling=2, progressive=True), dict(quality=30, subsampling=1, optimize=True),
+                       dict(quality=80, subsampling=2, restart_marker_blocks=3)):
+                if mode != "RGB":
+                    kw = {k: v for k, v in kw.items() if k != "subsampling"}
+                buf = io.BytesIO()
+                jpeg_test_image(w, h, mode).save(buf, "JPEG", **kw)
+                path = tmp_path / "t.jpg"
+                path.write_bytes(buf.getvalue())
+                assert np.array_equal(scene_io.decode_image_rgba8(buf.getvalue()), sf.stbi_reference_rgba(path)), (w, h, mode, kw)
+                n += 1
+    assert n == 108
+
+
+def test_jpeg_and_image_decoder_errors():
+    g = np.load(os.path.join(G, "jpeg_stb_fixture.npz"))
+    data = g["jpg_0"].tobytes()
+    for bad in (data[:2], data[:40], b"\xff\xd8\xff\xc9" + data[4:], b"GIF89a" + bytes(32), data[:-(len(data) // 2)].replace(b"\xff\xc4", b"\xff\xcc", 1)):
+        try:
+            img = scene_io.decode_image_rgba8(bad)
+        except abi.PtamdError:
+            continue
+        assert img.shape[2] == 4  # (a scan cut short decodes to the rows that were present, as stb_image does)
+
+
+def test_gltf_import_decodes_jpeg_textures(tmp_path):
+    """A .glb whose base-colour texture is a JPEG in a bufferView (what Sponza-class assets ship)."""
+    g = np.load(os.path.join(G, "jpeg_stb_fixture.npz"))
+    b = sf.GltfBuilder()
+    tex = b.image_png(g["jpg_2"].tobytes(), embed="view")     # (the builder stores the bytes as given)
+    b.doc["images"][-1]["mimeType"] = "image/jpeg"
+    b.doc["materials"].append({"pbrMetallicRoughness": {"baseColorTexture": {"index": tex}}})
+    path = str(tmp_path / "jpeg_tex.glb")
+    b.write(path, glb=True)
+    sc = scene_io.SceneFile.empty().import_gltf(path)
+    sc.add_camera((0, 0, 3), (0, 0, 0))
+    t = snap_textures(sc.snapshot().struct)
+    want = g["rgba_2"]
+    assert (t[0][0], t[0][1], t[0][2]) == (want.shape[1], want.shape[0], abi.TEX_RGBA8_SRGB)
+    assert t[0][3] == want.tobytes()

@@ -8,5 +8,5 @@ make -s all
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-result"
 /opt/rocm/bin/hipcc $F "$@" -c kernels.hip -o /tmp/kernels_$tag.o
 /opt/rocm/bin/hipcc $F "$@" -c renderer.hip -o /tmp/renderer_$tag.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libptamd_$tag.so /tmp/renderer_$tag.o /tmp/kernels_$tag.o lbvh.o scene_io.o scene_gltf.o scene_image.o -lz
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libptamd_$tag.so /tmp/renderer_$tag.o /tmp/kernels_$tag.o multi_device.o lbvh.o scene_io.o scene_gltf.o scene_image.o scene_jpeg.o -lz -ldl -lpthread
 echo built libptamd_$tag.so

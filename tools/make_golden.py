@@ -15,6 +15,8 @@ as small fixtures under tests/golden/.  Re-running must reproduce the files bit-
   scene_fixture/mini.*    a scene.json + _data.bin pair in the reference's format (tests/scene_formats.py restates saveToFile)
   exr_piz_fixture.exr/npz a 96x48 RGB half PIZ OpenEXR ENCODED by the reference's tinyexr (oracle/_ref/exrwrite) and the RGBA floats its
                           LoadEXR decodes from it (oracle/_ref/exr2raw)
+  jpeg_stb_fixture.npz    nine small JPEG files (baseline / progressive, 4:4:4 / 4:2:2 / 4:2:0, grey, CMYK, restart markers) and the RGBA8
+                          the reference's vendored stb_image (oracle/_ref/stbi2raw) decodes from each
   n3_textured_golden.npz  scenes.textured_scene() (textures, normal map, cut-outs, environment), 96x54, 6 bounces: accumulator
                           at 2 spp, per-bounce hit ids of sample 0, the environment alias table
 """
@@ -92,5 +94,26 @@ if os.path.exists(exrwrite) and os.path.exists(exr2raw):
         np.savez_compressed(os.path.join(G, "exr_piz_fixture.npz"), rgba=sf.tinyexr_reference_rgba(os.path.join(G, "exr_piz_fixture.exr"), td))
 else:
     print("oracle/_ref/exrwrite not built: exr_piz_fixture left as is")
+# ---- N4: JPEG files (encoded by PIL / libjpeg: test infrastructure) and the RGBA8 the REFERENCE's stb_image decodes from them ----
+stbi2raw = os.path.join(ROOT, "oracle", "_ref", "stbi2raw")
+try:
+    from PIL import Image
+except Exception:
+    Image = None
+if os.path.exists(stbi2raw) and Image is not None:
+    import io, subprocess, tempfile
+    fx = {}
+    for k, (w, h, mode, kw) in enumerate(tsi.jpeg_fixture_cases()):
+        buf = io.BytesIO()
+        tsi.jpeg_test_image(w, h, mode).save(buf, "JPEG", **kw)
+        data = buf.getvalue()
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "t.jpg")
+            open(path, "wb").write(data)
+            fx[f"jpg_{k}"] = np.frombuffer(data, np.uint8)
+            fx[f"rgba_{k}"] = sf.stbi_reference_rgba(path)
+    np.savez_compressed(os.path.join(G, "jpeg_stb_fixture.npz"), **fx)
+else:
+    print("oracle/_ref/stbi2raw or PIL missing: jpeg_stb_fixture.npz left as is")
 for f in sorted(os.listdir(G)):
     print(f, os.path.getsize(os.path.join(G, f)))
