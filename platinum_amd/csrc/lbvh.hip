@@ -207,11 +207,9 @@ __global__ void __launch_bounds__(256) k_refit(int n, const uint2* __restrict__ 
 // binary index, so refs need no remapping.
 __global__ void __launch_bounds__(256) k_emit(int n, const uint2* __restrict__ children, const uint32_t* __restrict__ parent_int,
                                                const Box* __restrict__ leaf_boxes, const uint32_t* __restrict__ order,
-                                               const Box* __restrict__ node_boxes, const TriRec* __restrict__ tris_in,
-                                               BvhNode* __restrict__ nodes, TriRec* __restrict__ tris_out,
-                                               uint32_t* __restrict__ emitted) {
+                                               const Box* __restrict__ node_boxes, BvhNode* __restrict__ nodes, uint32_t ref_base,
+                                               uint32_t leaf_tag, uint32_t remap, uint32_t* __restrict__ emitted) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) tris_out[i] = tris_in[order[i]];
   if (i >= n - 1) return;
   uint32_t depth = 0;
   for (uint32_t p = (uint32_t)i; p != 0; p = parent_int[p]) depth++;
@@ -224,7 +222,8 @@ __global__ void __launch_bounds__(256) k_emit(int n, const uint2* __restrict__ c
     Box3 e;
     for (int a = 0; a < 3; a++) { e.lo[a] = b.lo[a]; e.hi[a] = b.hi[a]; }
     boxes[count] = inflate_box(e);
-    refs[count] = ref;
+    if (ref & kLeafBit) { const uint32_t pos = ref & ~kLeafBit; refs[count] = leaf_tag | (remap ? order[pos] : pos); }
+    else refs[count] = ref_base + ref;
     count++;
   };
   const uint2 ch = children[i];
@@ -244,17 +243,20 @@ __global__ void __launch_bounds__(256) k_emit(int n, const uint2* __restrict__ c
 
 // Surface-area-guided collapse, one tree level per launch: the 4-wide node rooted at binary node i starts from i's two
 // children and keeps opening the internal child with the largest surface area until four slots are used (the even-depth
-// rule above opens both children blindly).  Internal children are appended to the next level's queue.  On Morton trees
-// this visits 5-13 % fewer nodes per ray (measured with the host build of the same traversal: C2 7.73 -> 7.37, a 259 k
-// triangle field 11.3 -> 10.5, the atrium 17.0 -> 14.8).
-__global__ void __launch_bounds__(256) k_emit_sah(uint32_t n_in, const uint32_t* __restrict__ q_in, uint32_t* __restrict__ q_out,
-                                                   uint32_t* __restrict__ n_out, const uint2* __restrict__ children,
-                                                   const Box* __restrict__ leaf_boxes, const uint32_t* __restrict__ order,
-                                                   const Box* __restrict__ node_boxes, BvhNode* __restrict__ nodes,
-                                                   uint32_t* __restrict__ emitted) {
+// rule above opens both children blindly).  On Morton trees this visits 5-13 % fewer nodes per ray (measured with the host
+// build of the same traversal: C2 7.73 -> 7.37, a 259 k triangle field 11.3 -> 10.5, the atrium 17.0 -> 14.8).
+// Nodes are written DENSELY, level by level: the level's queue holds (binary node, dense index) pairs; an internal child gets
+// the dense index next_base + its position in the next level's queue.  The 4-wide tree therefore occupies node_count
+// consecutive 64-byte records with the top levels first (C3: 506 175 nodes = 32 MB instead of the 66 MB of n - 1 slots, and a
+// small tree can be copied into LDS as it stands).  Leaf refs: leaf_tag | (remap ? order[sorted position] : sorted position).
+__global__ void __launch_bounds__(256) k_emit_sah(uint32_t n_in, const uint2* __restrict__ q_in, uint2* __restrict__ q_out,
+                                                   uint32_t* __restrict__ n_out, uint32_t next_base, uint32_t ref_base, uint32_t leaf_tag,
+                                                   uint32_t remap, const uint2* __restrict__ children, const Box* __restrict__ leaf_boxes,
+                                                   const uint32_t* __restrict__ order, const Box* __restrict__ node_boxes,
+                                                   BvhNode* __restrict__ nodes) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= n_in) return;
-  const uint32_t i = q_in[t];
+  const uint32_t i = q_in[t].x, dense = q_in[t].y;
   auto box_of = [&](uint32_t ref) { return (ref & kLeafBit) ? leaf_boxes[order[ref & ~kLeafBit]] : node_boxes[ref]; };
   auto half_area = [](const Box& b) {
     const float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
@@ -281,18 +283,23 @@ __global__ void __launch_bounds__(256) k_emit_sah(uint32_t n_in, const uint32_t*
     Box3 e;
     for (int a = 0; a < 3; a++) { e.lo[a] = bx[k].lo[a]; e.hi[a] = bx[k].hi[a]; }
     boxes[k] = inflate_box(e);
+    if (refs[k] & kLeafBit) {
+      const uint32_t pos = refs[k] & ~kLeafBit;
+      refs[k] = leaf_tag | (remap ? order[pos] : pos);
+    } else {
+      const uint32_t p = atomicAdd(n_out, 1u);
+      q_out[p] = make_uint2(refs[k], next_base + p);
+      refs[k] = ref_base + next_base + p;
+    }
   }
-  nodes[i] = quantize_node4(boxes, refs, count);
-  for (int k = 0; k < count; k++)
-    if (!(refs[k] & kLeafBit)) q_out[atomicAdd(n_out, 1u)] = refs[k];
-  atomicAdd(emitted, 1u);
+  nodes[dense] = quantize_node4(boxes, refs, count);
 }
 __global__ void __launch_bounds__(256) k_reorder_tris(int n, const uint32_t* __restrict__ order, const TriRec* __restrict__ tris_in,
                                                        TriRec* __restrict__ tris_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) tris_out[i] = tris_in[order[i]];
 }
-__global__ void k_seed_queue(uint32_t* q, uint32_t* counters, uint32_t root) { q[0] = root; counters[0] = 0u; counters[1] = 0u; }
+__global__ void k_seed_queue(uint2* q, uint32_t* counters, uint32_t root) { q[0] = make_uint2(root, 0u); counters[0] = 0u; counters[1] = 0u; }
 
 // ---- PLOC: parallel locally-ordered clustering (Meister & Bittner 2018) over the Morton order -----------------------------
 // Every cluster looks +-kPlocRadius positions around itself for the neighbour whose union with it has the smallest surface
@@ -300,7 +307,10 @@ __global__ void k_seed_queue(uint32_t* q, uint32_t* counters, uint32_t root) { q
 // search repeats until one cluster is left.  Node indices and positions come from prefix sums, so the tree is the same on
 // every run.  Against the Karras radix tree over the same order: 11-17 % fewer node visits and 7-21 % fewer triangle tests
 // per ray (host build of the same traversal, tests/emu EMU_PLOC).
-constexpr int kPlocRadius = 8;
+#ifndef PT_PLOC_RADIUS
+#define PT_PLOC_RADIUS 8
+#endif
+constexpr int kPlocRadius = PT_PLOC_RADIUS;
 __device__ __forceinline__ float merged_half_area(const Box& a, const Box& b) {
   const float x = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]);
   const float y = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]);
@@ -413,41 +423,37 @@ done:
   return err;
 }
 
-}  // namespace
 
-hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_count, uint32_t tri_count, uint32_t stack_capacity,
-                      LbvhResult* out) {
-  *out = LbvhResult{};
-  if (tri_count == 0) return hipSuccess;
+// ---- one tree ------------------------------------------------------------------------------------------------------------
+struct TreeInfo { uint32_t root_ref = kInvalidRef, node_span = 0, depth4 = 0; };
+
+// A 4-wide quantised BVH over n >= 1 leaf boxes (device memory), written at nodes_out[0 .. node_span): Morton order (rocPRIM
+// radix sort) -> PLOC binary tree (Karras radix tree as the fallback) -> SAH-guided 4-wide collapse, dense in BFS order.
+// Internal child refs are `ref_base + index`, leaf refs `leaf_tag | id` with id = the leaf's index in leaf_boxes[] when
+// `remap`, its position in the Morton order otherwise (the caller then reorders its leaf array by order_out[], n entries,
+// sorted position -> index).  nodes_out needs room for n - 1 records.
+static hipError_t build_tree(hipStream_t s, uint32_t n, const Box* leaf_boxes, uint32_t stack_capacity, bool use_ploc, BvhNode* nodes_out,
+                             uint32_t ref_base, uint32_t leaf_tag, bool remap, uint32_t* order_out, TreeInfo* info) {
   hipError_t err = hipSuccess;
-  const uint32_t n = tri_count;
+  *info = TreeInfo{};
   const uint32_t blocks = (n + 255) / 256;
-  TriRec* tris_tmp = nullptr; Box* leaf_boxes = nullptr; Box* node_boxes = nullptr;
+  Box* node_boxes = nullptr;
   uint64_t *keys_a = nullptr, *keys_b = nullptr; uint32_t *vals_a = nullptr, *vals_b = nullptr;
-  uint2* children = nullptr; uint32_t *parent_int = nullptr, *parent_leaf = nullptr, *flags = nullptr;
-  int* bounds = nullptr; uint32_t* max_depth = nullptr; void* sort_tmp = nullptr; size_t sort_bytes = 0;
+  uint2 *children = nullptr, *queue[2] = {nullptr, nullptr}; uint32_t *parent_int = nullptr, *parent_leaf = nullptr, *flags = nullptr;
+  int* bounds = nullptr; uint32_t* counters = nullptr; void* sort_tmp = nullptr; size_t sort_bytes = 0;
   uint32_t depth_h[2] = {0, 0};
-  uint32_t root = 0;
-  bool use_ploc = getenv("PTAMD_RADIX_TREE") == nullptr;  // PLOC by default; the Karras radix tree is the fallback
-
-  LB_CHECK(hipMalloc(&tris_tmp, sizeof(TriRec) * (size_t)n));
-  LB_CHECK(hipMalloc(&out->tris, sizeof(TriRec) * (size_t)n));
-  LB_CHECK(hipMalloc(&leaf_boxes, sizeof(Box) * (size_t)n));
-  LB_CHECK(hipMalloc(&bounds, sizeof(int) * 8));
-  LB_CHECK(hipMalloc(&max_depth, 4 * sizeof(uint32_t)));  // [0] max binary depth, [1] emitted 4-wide nodes (fallback), [2..3] BFS counters
-  LB_CHECK(hipMemsetAsync(max_depth, 0, 4 * sizeof(uint32_t), s));
-  hipLaunchKernelGGL(k_flatten, dim3(blocks), dim3(256), 0, s, S, instance_count, n, tris_tmp, leaf_boxes);
+  uint32_t root = 0, binary_depth = 0;
 
   if (n == 1) {
-    LB_CHECK(hipMemcpyAsync(out->tris, tris_tmp, sizeof(TriRec), hipMemcpyDeviceToDevice, s));
-    out->root_ref = kLeafBit | 0u;
-    out->node_count = 0;
-    out->max_depth = 1;
-    out->depth4 = 0;
+    const uint32_t zero = 0;
+    if (order_out) LB_CHECK(hipMemcpyAsync(order_out, &zero, sizeof(uint32_t), hipMemcpyHostToDevice, s));
     LB_CHECK(hipStreamSynchronize(s));
-    goto done;
+    info->root_ref = leaf_tag | 0u;
+    return hipSuccess;
   }
-
+  LB_CHECK(hipMalloc(&bounds, sizeof(int) * 8));
+  LB_CHECK(hipMalloc(&counters, 4 * sizeof(uint32_t)));  // [0] max binary depth, [1] emitted (fallback), [2] next level size, [3] unused
+  LB_CHECK(hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), s));
   LB_CHECK(hipMalloc(&keys_a, sizeof(uint64_t) * (size_t)n));
   LB_CHECK(hipMalloc(&keys_b, sizeof(uint64_t) * (size_t)n));
   LB_CHECK(hipMalloc(&vals_a, sizeof(uint32_t) * (size_t)n));
@@ -457,13 +463,11 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
   LB_CHECK(hipMalloc(&parent_leaf, sizeof(uint32_t) * (size_t)n));
   LB_CHECK(hipMalloc(&flags, sizeof(uint32_t) * (size_t)(n - 1)));
   LB_CHECK(hipMalloc(&node_boxes, sizeof(Box) * (size_t)(n - 1)));
-  LB_CHECK(hipMalloc(&out->nodes, sizeof(BvhNode) * (size_t)(n - 1)));
-  LB_CHECK(hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)(n - 1), s));
+  for (int k = 0; k < 2; k++) LB_CHECK(hipMalloc(&queue[k], sizeof(uint2) * (size_t)n));
 
   hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, s, bounds);
   hipLaunchKernelGGL(k_bounds, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, s, leaf_boxes, n, bounds);
   hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, s, leaf_boxes, n, bounds, keys_a, vals_a);
-
   LB_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 63, s));
   LB_CHECK(hipMalloc(&sort_tmp, sort_bytes));
   LB_CHECK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 63, s));
@@ -473,62 +477,97 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
       bool ok = false;
       LB_CHECK(ploc_build(s, n, leaf_boxes, vals_b, children, node_boxes, &root, &ok));
       if (!ok) { use_ploc = false; continue; }
-      out->max_depth = 0;  // (the binary depth is not tracked on this path; depth4 is what bounds the traversal stack)
     } else {
       LB_CHECK(hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)(n - 1), s));
-      LB_CHECK(hipMemsetAsync(max_depth, 0, 4 * sizeof(uint32_t), s));
+      LB_CHECK(hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), s));
       hipLaunchKernelGGL(k_karras, dim3(blocks), dim3(256), 0, s, keys_b, (int)n, children, parent_int, parent_leaf);
       hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, s, (int)n, children, parent_int, parent_leaf, leaf_boxes, vals_b,
-                         node_boxes, flags, max_depth);
-      LB_CHECK(hipMemcpyAsync(depth_h, max_depth, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                         node_boxes, flags, counters);
+      LB_CHECK(hipMemcpyAsync(depth_h, counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
       LB_CHECK(hipStreamSynchronize(s));
-      out->max_depth = depth_h[0];
+      binary_depth = depth_h[0];
       root = 0;
     }
-    // level-synchronous SAH collapse; queues live in the sort's scratch (vals_a: 4n bytes, keys_a: 8n bytes)
-    uint32_t* q_in = vals_a;
-    uint32_t* q_out = reinterpret_cast<uint32_t*>(keys_a);
-    uint32_t* counters = max_depth + 2;  // [0] next level's size, [1] nodes emitted
-    hipLaunchKernelGGL(k_seed_queue, dim3(1), dim3(1), 0, s, q_in, counters, root);
+    // level-synchronous SAH collapse, dense BFS numbering
+    uint2 *q_in = queue[0], *q_out = queue[1];
+    hipLaunchKernelGGL(k_seed_queue, dim3(1), dim3(1), 0, s, q_in, counters + 2, root);
     uint32_t n_in = 1, levels = 0, emitted = 0;
     bool too_deep = false;
     while (n_in > 0) {
       if ((levels + 1) * 3 > stack_capacity) { too_deep = true; break; }
-      hipLaunchKernelGGL(k_emit_sah, dim3((n_in + 255) / 256), dim3(256), 0, s, n_in, q_in, q_out, counters, children, leaf_boxes, vals_b,
-                         node_boxes, out->nodes, counters + 1);
-      uint32_t h[2];
-      LB_CHECK(hipMemcpyAsync(h, counters, sizeof(h), hipMemcpyDeviceToHost, s));
-      LB_CHECK(hipMemsetAsync(counters, 0, sizeof(uint32_t), s));
+      hipLaunchKernelGGL(k_emit_sah, dim3((n_in + 255) / 256), dim3(256), 0, s, n_in, q_in, q_out, counters + 2, emitted + n_in, ref_base,
+                         leaf_tag, remap ? 1u : 0u, children, leaf_boxes, vals_b, node_boxes, nodes_out);
+      uint32_t h = 0;
+      LB_CHECK(hipMemcpyAsync(&h, counters + 2, sizeof(h), hipMemcpyDeviceToHost, s));
+      LB_CHECK(hipMemsetAsync(counters + 2, 0, sizeof(uint32_t), s));
       LB_CHECK(hipStreamSynchronize(s));
-      n_in = h[0]; emitted = h[1];
+      emitted += n_in;
+      n_in = h;
       std::swap(q_in, q_out);
       levels++;
     }
     if (too_deep && use_ploc) { use_ploc = false; continue; }  // a pathological cluster tree: try the radix tree
     if (too_deep) {
-      // pathological radix tree: the even-depth collapse bounds the 4-wide depth by half the binary depth
-      LB_CHECK(hipMemsetAsync(max_depth + 1, 0, sizeof(uint32_t), s));
-      hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, s, (int)n, children, parent_int, leaf_boxes, vals_b, node_boxes, tris_tmp,
-                         out->nodes, out->tris, max_depth + 1);
-      LB_CHECK(hipMemcpyAsync(depth_h, max_depth, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-      LB_CHECK(hipStreamSynchronize(s));
-      emitted = depth_h[1];
-      levels = (out->max_depth + 1) / 2;
+      // pathological radix tree: the even-depth collapse bounds the 4-wide depth by half the binary depth (nodes keep their
+      // binary index: the tree spans n - 1 slots)
+      LB_CHECK(hipMemsetAsync(counters + 1, 0, sizeof(uint32_t), s));
+      hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, s, (int)n, children, parent_int, leaf_boxes, vals_b, node_boxes, nodes_out, ref_base,
+                         leaf_tag, remap ? 1u : 0u, counters + 1);
+      emitted = n - 1;
+      levels = (binary_depth + 1) / 2;
+      info->root_ref = ref_base + 0u;
     } else {
-      hipLaunchKernelGGL(k_reorder_tris, dim3(blocks), dim3(256), 0, s, (int)n, vals_b, tris_tmp, out->tris);
+      info->root_ref = ref_base + 0u;  // the root is dense node 0
     }
+    if (order_out) LB_CHECK(hipMemcpyAsync(order_out, vals_b, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
     LB_CHECK(hipGetLastError());
     LB_CHECK(hipStreamSynchronize(s));
-    out->root_ref = root;
-    out->node_count = emitted;
-    out->depth4 = levels;
+    info->node_span = emitted;
+    info->depth4 = levels;
     break;
   }
 
 done:
-  (void)hipFree(tris_tmp); (void)hipFree(leaf_boxes); (void)hipFree(node_boxes); (void)hipFree(keys_a); (void)hipFree(keys_b); (void)hipFree(vals_a);
-  (void)hipFree(vals_b); (void)hipFree(children); (void)hipFree(parent_int); (void)hipFree(parent_leaf); (void)hipFree(flags); (void)hipFree(bounds);
-  (void)hipFree(max_depth); (void)hipFree(sort_tmp);
+  (void)hipFree(node_boxes); (void)hipFree(keys_a); (void)hipFree(keys_b); (void)hipFree(vals_a); (void)hipFree(vals_b); (void)hipFree(children);
+  (void)hipFree(parent_int); (void)hipFree(parent_leaf); (void)hipFree(flags); (void)hipFree(bounds); (void)hipFree(counters); (void)hipFree(sort_tmp);
+  (void)hipFree(queue[0]); (void)hipFree(queue[1]);
+  return err;
+}
+
+}  // namespace
+
+// Flattens the instanced scene to world-space triangles and builds ONE BVH over them (the default: fewest node visits per ray).
+hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_count, uint32_t tri_count, uint32_t stack_capacity,
+                      LbvhResult* out) {
+  *out = LbvhResult{};
+  if (tri_count == 0) return hipSuccess;
+  hipError_t err = hipSuccess;
+  const uint32_t n = tri_count;
+  const uint32_t blocks = (n + 255) / 256;
+  TriRec* tris_tmp = nullptr; Box* leaf_boxes = nullptr; BvhNode* nodes_tmp = nullptr; uint32_t* order = nullptr;
+  TreeInfo info;
+  const bool use_ploc = getenv("PTAMD_RADIX_TREE") == nullptr;  // PLOC by default; the Karras radix tree is the fallback
+
+  LB_CHECK(hipMalloc(&tris_tmp, sizeof(TriRec) * (size_t)n));
+  LB_CHECK(hipMalloc(&out->tris, sizeof(TriRec) * (size_t)n));
+  LB_CHECK(hipMalloc(&leaf_boxes, sizeof(Box) * (size_t)n));
+  LB_CHECK(hipMalloc(&order, sizeof(uint32_t) * (size_t)n));
+  if (n > 1) LB_CHECK(hipMalloc(&nodes_tmp, sizeof(BvhNode) * (size_t)(n - 1)));
+  hipLaunchKernelGGL(k_flatten, dim3(blocks), dim3(256), 0, s, S, instance_count, n, tris_tmp, leaf_boxes);
+  LB_CHECK(build_tree(s, n, leaf_boxes, stack_capacity, use_ploc, nodes_tmp, 0u, kLeafBit, false, order, &info));
+  hipLaunchKernelGGL(k_reorder_tris, dim3(blocks), dim3(256), 0, s, (int)n, order, tris_tmp, out->tris);  // triangles in leaf (Morton) order
+  if (info.node_span) {  // keep exactly the records the tree uses
+    LB_CHECK(hipMalloc(&out->nodes, sizeof(BvhNode) * (size_t)info.node_span));
+    LB_CHECK(hipMemcpyAsync(out->nodes, nodes_tmp, sizeof(BvhNode) * (size_t)info.node_span, hipMemcpyDeviceToDevice, s));
+  }
+  LB_CHECK(hipGetLastError());
+  LB_CHECK(hipStreamSynchronize(s));
+  out->root_ref = info.root_ref;
+  out->node_count = info.node_span;
+  out->depth4 = info.depth4;
+
+done:
+  (void)hipFree(tris_tmp); (void)hipFree(leaf_boxes); (void)hipFree(nodes_tmp); (void)hipFree(order);
   if (err != hipSuccess) {
     (void)hipFree(out->nodes); (void)hipFree(out->tris);
     *out = LbvhResult{};
