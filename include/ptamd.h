@@ -254,7 +254,14 @@ typedef struct pt_render_params {
   uint32_t nonfinite_policy;   /* NEW: PT_NONFINITE_*: what a NaN/inf sample does to the running mean */
   void* external_accumulator;  /* optional DEVICE pointer to W*H float4; NULL = library-owned */
   void* stream;                /* optional hipStream_t to enqueue on; NULL = library-owned stream */
+  uint32_t accel_structure;    /* NEW (ABI 3): PT_ACCEL_*.  The reference always builds BLAS per mesh + TLAS over instances
+                                  (renderer_pt.cpp:653-749); closest hits are identical whichever structure is walked */
+  uint32_t _reserved;
 } pt_render_params;
+/* PT_ACCEL_AUTO: one BVH over the flattened world-space triangles (fastest: C3 7.4 vs 4.2 Grays/s) unless that would not fit
+ * beside the path queues; PT_ACCEL_TWO_LEVEL: TLAS over instances + one object-space BLAS per mesh (C3: 65 KB instead of 82 MB
+ * of nodes, staged in LDS by the trace kernels); needs invertible instance transforms, else one BVH is built. */
+enum { PT_ACCEL_AUTO = 0, PT_ACCEL_ONE_BVH = 1, PT_ACCEL_TWO_LEVEL = 2 };
 
 /* Renderer::startRender + the rebuild* half of the first Renderer::render() (renderer_pt.cpp:72-111,
  * 199-217): copies the snapshot to HBM, builds light table, constants and the LBVH.  The caller owns the
@@ -353,7 +360,7 @@ int pt_debug_sample(pt_renderer* r, uint32_t sample_idx, float* radiance_out, in
 typedef struct pt_stats {
   uint64_t triangles;          /* flattened world-space triangles */
   uint64_t bvh_nodes;
-  uint32_t bvh_max_depth;      /* levels of the 4-wide tree (the traversal stack holds <= 3 entries per level) */
+  uint32_t bvh_max_depth;      /* levels of the 4-wide tree (two-level: TLAS + deepest BLAS); the traversal stack holds <= 3 entries per level */
   uint32_t samples_in_flight;
   double upload_ms;            /* snapshot -> HBM */
   double bvh_build_ms;         /* LBVH build (device time) */
@@ -368,6 +375,8 @@ typedef struct pt_stats {
   /* instrumented traversal (pt_measure_traversal): mean BVH nodes / triangles fetched per ray */
   double nodes_per_closest_ray, tris_per_closest_ray;
   double nodes_per_shadow_ray, tris_per_shadow_ray;
+  uint32_t accel_two_level;    /* 1: the two-level structure is in use */
+  uint32_t _pad;
 } pt_stats;
 int pt_get_stats(pt_renderer* r, pt_stats* out);
 /* Enable per-kernel HIP-event timing (adds two event records per launch). */

@@ -18,6 +18,7 @@ FLAG_NONE, FLAG_MULTISCATTER_GGX, FLAG_GMON = 0, 1, 2
 # pt_shader_defs.hpp:85-90
 MATERIAL_THIN_DIELECTRIC, MATERIAL_USE_ALPHA, MATERIAL_EMISSIVE, MATERIAL_ANISOTROPIC = 1, 2, 4, 8
 NONFINITE_PROPAGATE, NONFINITE_ZERO = 0, 1
+ACCEL_AUTO, ACCEL_ONE_BVH, ACCEL_TWO_LEVEL = 0, 1, 2
 
 
 class Float3(C.Structure):
@@ -129,6 +130,7 @@ class RenderParams(C.Structure):
         ("flags", C.c_int32), ("integrator", C.c_uint32), ("working_space", Colorspace),
         ("max_bounces", C.c_uint32), ("first_sample", C.c_uint32), ("samples_in_flight", C.c_uint32),
         ("nonfinite_policy", C.c_uint32), ("external_accumulator", C.c_void_p), ("stream", C.c_void_p),
+        ("accel_structure", C.c_uint32), ("_reserved", C.c_uint32),
     ]
 
 
@@ -174,6 +176,7 @@ class Stats(C.Structure):
         ("ms_accumulate", C.c_double), ("launches_closest", C.c_uint64), ("launches_shadow", C.c_uint64),
         ("nodes_per_closest_ray", C.c_double), ("tris_per_closest_ray", C.c_double),
         ("nodes_per_shadow_ray", C.c_double), ("tris_per_shadow_ray", C.c_double),
+        ("accel_two_level", C.c_uint32), ("_pad", C.c_uint32),
     ]
 
 

@@ -33,6 +33,8 @@ void launch_raygen(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState
 // `bounce_closest`) and, if do_shadow, of the shadow queue consumed at `bounce_shadow`.
 void launch_chunk_tables(hipStream_t s, Segments seg, uint32_t cur, BatchCounters* ctr, uint32_t bounce_closest,
                          uint32_t bounce_shadow, bool do_shadow);
+uint32_t trace_block_threads(bool two_level);
+uint32_t trace_blocks_per_cu_two_level();  // 256 (7 blocks per CU) for one BVH, 1024 (one block per CU) for the two-level structure
 void launch_trace_closest(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, vec4* hit, Segments seg, uint32_t cur,
                           BatchCounters* ctr, uint32_t bounce, uint32_t* spill, int32_t* hitlog, uint32_t log_stride, bool count);
 // `grid` blocks of shade_block_threads() threads (a persistent grid: shade_blocks_per_cu() per CU keeps it resident)
@@ -57,8 +59,9 @@ void launch_hit_records(hipStream_t s, uint32_t grid, const DeviceScene& S, Path
 
 // ---- LBVH (lbvh.hip) ----
 struct LbvhResult {
-  BvhNode* nodes = nullptr;   // indexed like the binary radix tree (tri_count - 1 slots, even-depth ones used)
-  TriRec* tris = nullptr;     // tri_count records in leaf (Morton) order
+  BvhNode* nodes = nullptr;   // node_count records, the root first
+  TriRec* tris = nullptr;     // tri_count records: in leaf (Morton) order (one BVH), in flattening order (two-level)
+  MeshTrav* mesh_trav = nullptr;  // two-level only: one record per mesh
   uint32_t root_ref = kInvalidRef;
   uint32_t node_count = 0;    // 4-wide nodes emitted
   uint32_t max_depth = 0;     // of the binary tree
@@ -68,5 +71,10 @@ struct LbvhResult {
 // `S` needs positions / indices / meshes / instances filled in. Returns hipSuccess or the failing HIP error.
 hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_count, uint32_t tri_count, uint32_t stack_capacity,
                       LbvhResult* out);
+// The two-level structure: a TLAS over the instances' world boxes + one object-space BLAS per mesh, in one node array
+// (depth4 = TLAS levels + deepest BLAS levels; the traversal stack also holds one exit marker).  `meshes` is the host copy
+// of S.meshes (mesh_count entries).
+hipError_t build_two_level(hipStream_t s, const DeviceScene& S, const MeshInfo* meshes, uint32_t mesh_count, uint32_t instance_count,
+                           uint32_t tri_count, uint32_t stack_capacity, LbvhResult* out);
 
 }  // namespace pt

@@ -214,9 +214,32 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DeviceScene S, PathState st, 
 // exhausted with nobody else able to advance), every lane with a queued leaf runs ONE triangle test.  The triangle code
 // therefore executes with most lanes busy instead of whenever a single lane met a leaf.  A ray is finished when its node
 // stack is exhausted and its queue is empty (any-hit: on the first accepted hit).
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ void wave_traverse(const DeviceScene& S, TravState& ts, TraversalCount* tc) {
-  if (ts.cur != kInvalidRef && ts.st.npend <= kPendLeaves - 4) trav_node<COUNT>(S, ts, tc);
+#ifndef PT_TWO_BLOCK
+#define PT_TWO_BLOCK 1024
+#define PT_TWO_BLOCKS_PER_CU 1
+#define PT_TWO_LDS_NODES 1024
+#endif
+constexpr uint32_t kTraceBlock2 = PT_TWO_BLOCK;  // two-level kernels: ONE block per CU (4 waves per SIMD) sharing the staged node array
+constexpr uint32_t kLdsNodes = PT_TWO_LDS_NODES; // 64 KB of nodes in LDS beside the 88 KB of stacks and leaf queues of 1024 lanes (152 of 160 KB)
+template <bool ANY, bool COUNT, bool TWO>
+__device__ __forceinline__ void wave_traverse(const DeviceScene& S, const BvhNode* lds_nodes, TravState& ts, TraversalCount* tc) {
+  if (ts.cur != kInvalidRef && ts.st.npend <= kPendLeaves - 4) {
+    if (TWO) {
+      // Exit markers are handled at once; ENTERING an instance (two dependent loads, three divides) is voted on like the
+      // triangle tests: it runs when half of the lanes that can advance are waiting at an instance, or nobody has a node.
+      trav_leave(ts);
+      const bool at_inst = ts.cur != kInvalidRef && (ts.cur & kInstBit) != 0;
+      const bool at_node = ts.cur != kInvalidRef && !at_inst;
+      const unsigned long long mi = __ballot(at_inst), mn = __ballot(at_node);
+      if (mi != 0 && (2 * __popcll(mi) >= __popcll(mn) || mn == 0)) {
+        if (at_inst) trav_resolve(S, ts);
+      } else if (at_node) {
+        if (lds_nodes) trav_node<COUNT, true>(lds_nodes, ts, tc); else trav_node<COUNT, true>(S.nodes, ts, tc);
+      }
+    } else {
+      trav_node<COUNT, false>(S.nodes, ts, tc);
+    }
+  }
   const bool pending = ts.st.npend > 0;
   const bool stuck = pending && (ts.cur == kInvalidRef || ts.st.npend > kPendLeaves - 4);
   const bool advancing = ts.cur != kInvalidRef && !stuck;
@@ -229,23 +252,35 @@ __device__ __forceinline__ void wave_traverse(const DeviceScene& S, TravState& t
   }
 }
 
+// the two-level structure's nodes -> LDS (when they fit); returns the pointer the traversal should use (nullptr: HBM)
+__device__ __forceinline__ const BvhNode* stage_nodes(const DeviceScene& S, BvhNode* lds_nodes) {
+  if (S.node_count > kLdsNodes) return nullptr;
+  const uint4* src = reinterpret_cast<const uint4*>(S.nodes);
+  uint4* dst = reinterpret_cast<uint4*>(lds_nodes);
+  for (uint32_t i = threadIdx.x; i < S.node_count * 4; i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+  return lds_nodes;
+}
+
 // ---- closest hit ---------------------------------------------------------------------------------------------------
-template <bool COUNT>
-__global__ void __launch_bounds__(kBlock, PT_TRACE_WAVES) k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments seg,
-                                                           uint32_t cur, BatchCounters* __restrict__ ctr, uint32_t bounce,
-                                                           uint32_t* __restrict__ spill, int32_t* __restrict__ hitlog,
-                                                           uint32_t log_stride) {
-  __shared__ uint32_t lds_stack[kLdsStack + 1][kBlock];
-  __shared__ uint32_t lds_pend[kPendLeaves + 1][kBlock];
+template <bool COUNT, bool TWO>
+__global__ void __launch_bounds__(TWO ? kTraceBlock2 : kBlock, TWO ? PT_TWO_BLOCKS_PER_CU : PT_TRACE_WAVES)
+k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments seg, uint32_t cur, BatchCounters* __restrict__ ctr, uint32_t bounce,
+                uint32_t* __restrict__ spill, int32_t* __restrict__ hitlog, uint32_t log_stride) {
+  constexpr uint32_t kTB = TWO ? kTraceBlock2 : kBlock;
+  __shared__ uint32_t lds_stack[kLdsStack + 1][kTB];
+  __shared__ uint32_t lds_pend[kPendLeaves + 1][kTB];
+  __shared__ BvhNode lds_nodes_buf[TWO && kLdsNodes ? kLdsNodes : 1];
+  const BvhNode* lds_nodes = TWO && kLdsNodes ? stage_nodes(S, lds_nodes_buf) : nullptr;
   const uint32_t lane = wave_lane();
   ChunkClaims src;
   src.init(seg.table_closest, ctr->chunks_closest[bounce], seg.active[cur], &ctr->work_closest[bounce], seg, lane);
   TraversalStack stack;
   stack.lds = &lds_stack[0][threadIdx.x];
   stack.pend = &lds_pend[0][threadIdx.x];
-  stack.lds_stride = kBlock;
-  stack.spill = spill + ((size_t)blockIdx.x * kBlock + threadIdx.x);
-  stack.spill_stride = gridDim.x * kBlock;
+  stack.lds_stride = kTB;
+  stack.spill = spill + ((size_t)blockIdx.x * kTB + threadIdx.x);
+  stack.spill_stride = gridDim.x * kTB;
   TraversalCount tc;
 
   // (written as an explicit init / step loop: with the whole traversal behind one call the compiler produced a kernel
@@ -279,7 +314,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_WAVES) k_trace_closest(Device
       continue;
     }
     while (ray != kInvalidRef) {
-      wave_traverse<false, COUNT>(S, ts, &tc);
+      wave_traverse<false, COUNT, TWO>(S, lds_nodes, ts, &tc);
       if (ts.cur == kInvalidRef && ts.st.npend == 0) finish();
       // lanes still in this loop vote: leave for a refill once the wave has emptied below the threshold
       if (refill && !src.exhausted && (uint32_t)__popcll(__ballot(ray != kInvalidRef)) < refill) break;
@@ -477,21 +512,24 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
 }
 
 // ---- shadow (any hit) --------------------------------------------------------------------------------------------------
-template <bool COUNT>
-__global__ void __launch_bounds__(kBlock, PT_TRACE_WAVES) k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments seg,
-                                                          BatchCounters* __restrict__ ctr, uint32_t bounce,
-                                                          uint32_t* __restrict__ spill) {
-  __shared__ uint32_t lds_stack[kLdsStack + 1][kBlock];
-  __shared__ uint32_t lds_pend[kPendLeaves + 1][kBlock];
+template <bool COUNT, bool TWO>
+__global__ void __launch_bounds__(TWO ? kTraceBlock2 : kBlock, TWO ? PT_TWO_BLOCKS_PER_CU : PT_TRACE_WAVES)
+k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments seg, BatchCounters* __restrict__ ctr, uint32_t bounce,
+               uint32_t* __restrict__ spill) {
+  constexpr uint32_t kTB = TWO ? kTraceBlock2 : kBlock;
+  __shared__ uint32_t lds_stack[kLdsStack + 1][kTB];
+  __shared__ uint32_t lds_pend[kPendLeaves + 1][kTB];
+  __shared__ BvhNode lds_nodes_buf[TWO && kLdsNodes ? kLdsNodes : 1];
+  const BvhNode* lds_nodes = TWO && kLdsNodes ? stage_nodes(S, lds_nodes_buf) : nullptr;
   const uint32_t lane = wave_lane();
   ChunkClaims src;
   src.init(seg.table_shadow, ctr->chunks_shadow[bounce], seg.shadow, &ctr->work_shadow[bounce], seg, lane);
   TraversalStack stack;
   stack.lds = &lds_stack[0][threadIdx.x];
   stack.pend = &lds_pend[0][threadIdx.x];
-  stack.lds_stride = kBlock;
-  stack.spill = spill + ((size_t)blockIdx.x * kBlock + threadIdx.x);
-  stack.spill_stride = gridDim.x * kBlock;
+  stack.lds_stride = kTB;
+  stack.spill = spill + ((size_t)blockIdx.x * kTB + threadIdx.x);
+  stack.spill_stride = gridDim.x * kTB;
   TraversalCount tc;
 
   // (written as an explicit init / step loop: with the whole traversal behind one call the compiler produced a kernel
@@ -523,7 +561,7 @@ __global__ void __launch_bounds__(kBlock, PT_TRACE_WAVES) k_trace_shadow(DeviceS
       continue;
     }
     while (ray != kInvalidRef) {
-      wave_traverse<true, COUNT>(S, ts, &tc);
+      wave_traverse<true, COUNT, TWO>(S, lds_nodes, ts, &tc);
       if (ts.cur == kInvalidRef && ts.st.npend == 0) finish();
       if (refill && !src.exhausted && (uint32_t)__popcll(__ballot(ray != kInvalidRef)) < refill) break;
     }
@@ -716,12 +754,22 @@ void launch_chunk_tables(hipStream_t s, Segments seg, uint32_t cur, BatchCounter
                          uint32_t bounce_shadow, bool do_shadow) {
   hipLaunchKernelGGL(k_chunk_tables, dim3(kTableBlocks, 2), dim3(1024), 0, s, seg, cur, ctr, bounce_closest, bounce_shadow, do_shadow ? 1u : 0u);
 }
+// One-BVH scenes: `grid` blocks of 256 threads (7 per CU).  Two-level scenes (S.two_level): one 1024-thread block per CU.
+uint32_t trace_block_threads(bool two_level) { return two_level ? kTraceBlock2 : (uint32_t)kBlock; }
+uint32_t trace_blocks_per_cu_two_level() { return PT_TWO_BLOCKS_PER_CU; }
 void launch_trace_closest(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, vec4* hit, Segments seg, uint32_t cur,
                           BatchCounters* ctr, uint32_t bounce, uint32_t* spill, int32_t* hitlog, uint32_t log_stride, bool count) {
+  if (S.two_level) {
+    if (count)
+      hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(grid), dim3(kTraceBlock2), 0, s, S, st, hit, seg, cur, ctr, bounce, spill, hitlog, log_stride);
+    else
+      hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(kTraceBlock2), 0, s, S, st, hit, seg, cur, ctr, bounce, spill, hitlog, log_stride);
+    return;
+  }
   if (count)
-    hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(kBlock), 0, s, S, st, hit, seg, cur, ctr, bounce, spill, hitlog, log_stride);
+    hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(grid), dim3(kBlock), 0, s, S, st, hit, seg, cur, ctr, bounce, spill, hitlog, log_stride);
   else
-    hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(kBlock), 0, s, S, st, hit, seg, cur, ctr, bounce, spill, hitlog, log_stride);
+    hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid), dim3(kBlock), 0, s, S, st, hit, seg, cur, ctr, bounce, spill, hitlog, log_stride);
 }
 uint32_t shade_block_threads() { return kShadeBlock; }
 uint32_t shade_blocks_per_cu() { return (PT_SHADE_WAVES * 4 * 64) / PT_SHADE_BLOCK; }
@@ -731,10 +779,13 @@ void launch_shade(hipStream_t s, uint32_t grid, const DeviceScene* S, PathState 
 }
 void launch_trace_shadow(hipStream_t s, uint32_t grid, const DeviceScene& S, ShadowQueue sq, vec4* Lbuf, Segments seg,
                          BatchCounters* ctr, uint32_t bounce, uint32_t* spill, bool count) {
-  if (count)
-    hipLaunchKernelGGL(k_trace_shadow<true>, dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, seg, ctr, bounce, spill);
-  else
-    hipLaunchKernelGGL(k_trace_shadow<false>, dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, seg, ctr, bounce, spill);
+  if (S.two_level) {
+    if (count) hipLaunchKernelGGL((k_trace_shadow<true, true>), dim3(grid), dim3(kTraceBlock2), 0, s, S, sq, Lbuf, seg, ctr, bounce, spill);
+    else hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(grid), dim3(kTraceBlock2), 0, s, S, sq, Lbuf, seg, ctr, bounce, spill);
+    return;
+  }
+  if (count) hipLaunchKernelGGL((k_trace_shadow<true, false>), dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, seg, ctr, bounce, spill);
+  else hipLaunchKernelGGL((k_trace_shadow<false, false>), dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, seg, ctr, bounce, spill);
 }
 void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npixels, uint32_t nsamples, uint32_t n0,
                        uint32_t nonfinite_policy, BatchCounters* ctr) {

@@ -575,4 +575,122 @@ done:
   return err;
 }
 
+
+namespace {
+// world box of every instance = union of its flattened triangles' boxes (one block per instance)
+__global__ void __launch_bounds__(256) k_instance_boxes(DeviceScene S, const Box* __restrict__ tri_boxes, Box* __restrict__ inst_boxes) {
+  const InstanceInfo inst = S.instances[blockIdx.x];
+  const uint32_t n = S.meshes[inst.mesh].tri_count;
+  float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+  for (uint32_t t = threadIdx.x; t < n; t += 256) {
+    const Box b = tri_boxes[inst.tri_global_base + t];
+    for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], b.lo[k]); hi[k] = fmaxf(hi[k], b.hi[k]); }
+  }
+  __shared__ float red[6][256];
+  for (int k = 0; k < 3; k++) { red[k][threadIdx.x] = lo[k]; red[3 + k][threadIdx.x] = hi[k]; }
+  __syncthreads();
+  for (uint32_t off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off)
+      for (int k = 0; k < 3; k++) {
+        red[k][threadIdx.x] = fminf(red[k][threadIdx.x], red[k][threadIdx.x + off]);
+        red[3 + k][threadIdx.x] = fmaxf(red[3 + k][threadIdx.x], red[3 + k][threadIdx.x + off]);
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    Box b;
+    for (int k = 0; k < 3; k++) { b.lo[k] = red[k][0]; b.hi[k] = red[3 + k][0]; }
+    b._pad[0] = b._pad[1] = 0.0f;
+    inst_boxes[blockIdx.x] = b;
+  }
+}
+// object-space boxes of one mesh's triangles
+__global__ void __launch_bounds__(256) k_mesh_boxes(DeviceScene S, MeshInfo mesh, Box* __restrict__ boxes) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= mesh.tri_count) return;
+  const uint32_t* idx = &S.indices[3 * (size_t)(mesh.tri_base + t)];
+  const vec3 v0 = ld3(S.positions[mesh.vertex_base + idx[0]]), v1 = ld3(S.positions[mesh.vertex_base + idx[1]]),
+             v2 = ld3(S.positions[mesh.vertex_base + idx[2]]);
+  Box b;
+  b.lo[0] = fminf(v0.x, fminf(v1.x, v2.x)); b.hi[0] = fmaxf(v0.x, fmaxf(v1.x, v2.x));
+  b.lo[1] = fminf(v0.y, fminf(v1.y, v2.y)); b.hi[1] = fmaxf(v0.y, fmaxf(v1.y, v2.y));
+  b.lo[2] = fminf(v0.z, fminf(v1.z, v2.z)); b.hi[2] = fmaxf(v0.z, fmaxf(v1.z, v2.z));
+  b._pad[0] = b._pad[1] = 0.0f;
+  boxes[t] = b;
+}
+// the bounds a tree's root node spans (decoded exactly as the traversal decodes them: a superset of the leaf boxes)
+__global__ void k_root_bounds(const BvhNode* __restrict__ root, MeshTrav* __restrict__ out) {
+  const BvhNode n = *root;
+  for (int a = 0; a < 3; a++) {
+    uint32_t qlo = 255, qhi = 0;
+    for (int k = 0; k < 4; k++)
+      if (n.ref[k] != kInvalidRef) { qlo = min(qlo, (n.qlo[a] >> (8 * k)) & 0xffu); qhi = max(qhi, (n.qhi[a] >> (8 * k)) & 0xffu); }
+    out->lo[a] = n.origin[a] + (float)qlo * node_scale(n.exp[a]);
+    out->hi[a] = n.origin[a] + (float)qhi * node_scale(n.exp[a]);
+  }
+}
+__global__ void k_box_bounds(const Box* __restrict__ b, MeshTrav* __restrict__ out) {
+  const Box3 e = inflate_box(Box3{{b->lo[0], b->lo[1], b->lo[2]}, {b->hi[0], b->hi[1], b->hi[2]}});
+  for (int a = 0; a < 3; a++) { out->lo[a] = e.lo[a]; out->hi[a] = e.hi[a]; }
+}
+}  // namespace
+
+hipError_t build_two_level(hipStream_t s, const DeviceScene& S, const MeshInfo* meshes, uint32_t mesh_count, uint32_t instance_count,
+                           uint32_t tri_count, uint32_t stack_capacity, LbvhResult* out) {
+  *out = LbvhResult{};
+  if (tri_count == 0 || instance_count == 0) return hipSuccess;
+  hipError_t err = hipSuccess;
+  Box *tri_boxes = nullptr, *inst_boxes = nullptr, *mesh_boxes = nullptr;
+  BvhNode* nodes_tmp = nullptr;
+  TreeInfo tlas;
+  uint32_t base = 0, deepest_blas = 0, max_mesh_tris = 0;
+  size_t capacity = instance_count;
+  const bool use_ploc = getenv("PTAMD_RADIX_TREE") == nullptr;
+  std::vector<MeshTrav> mt(mesh_count);
+  for (uint32_t m = 0; m < mesh_count; m++) { capacity += meshes[m].tri_count; max_mesh_tris = std::max(max_mesh_tris, meshes[m].tri_count); }
+
+  LB_CHECK(hipMalloc(&out->tris, sizeof(TriRec) * (size_t)tri_count));
+  LB_CHECK(hipMalloc(&tri_boxes, sizeof(Box) * (size_t)tri_count));
+  LB_CHECK(hipMalloc(&inst_boxes, sizeof(Box) * (size_t)instance_count));
+  LB_CHECK(hipMalloc(&mesh_boxes, sizeof(Box) * (size_t)std::max(1u, max_mesh_tris)));
+  LB_CHECK(hipMalloc(&nodes_tmp, sizeof(BvhNode) * capacity));
+  LB_CHECK(hipMalloc(&out->mesh_trav, sizeof(MeshTrav) * (size_t)mesh_count));
+  LB_CHECK(hipMemsetAsync(out->mesh_trav, 0, sizeof(MeshTrav) * (size_t)mesh_count, s));
+  // world-space triangles in flattening order (the intersection contract's triangles) and the instances' world boxes
+  hipLaunchKernelGGL(k_flatten, dim3((tri_count + 255) / 256), dim3(256), 0, s, S, instance_count, tri_count, out->tris, tri_boxes);
+  hipLaunchKernelGGL(k_instance_boxes, dim3(instance_count), dim3(256), 0, s, S, tri_boxes, inst_boxes);
+  LB_CHECK(build_tree(s, instance_count, inst_boxes, stack_capacity, use_ploc, nodes_tmp, 0u, kInstBit, true, nullptr, &tlas));
+  base = tlas.node_span;
+  for (uint32_t m = 0; m < mesh_count; m++) {
+    const MeshInfo mesh = meshes[m];
+    if (mesh.tri_count == 0) { mt[m].root_ref = kInvalidRef; continue; }
+    TreeInfo blas;
+    hipLaunchKernelGGL(k_mesh_boxes, dim3((mesh.tri_count + 255) / 256), dim3(256), 0, s, S, mesh, mesh_boxes);
+    LB_CHECK(build_tree(s, mesh.tri_count, mesh_boxes, stack_capacity, use_ploc, nodes_tmp + base, base, kLeafBit, true, nullptr, &blas));
+    LB_CHECK(hipMemcpyAsync(&out->mesh_trav[m].root_ref, &blas.root_ref, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (blas.node_span) hipLaunchKernelGGL(k_root_bounds, dim3(1), dim3(1), 0, s, nodes_tmp + base, out->mesh_trav + m);
+    else hipLaunchKernelGGL(k_box_bounds, dim3(1), dim3(1), 0, s, mesh_boxes, out->mesh_trav + m);
+    LB_CHECK(hipStreamSynchronize(s));
+    base += blas.node_span;
+    deepest_blas = std::max(deepest_blas, blas.depth4);
+  }
+  if (base) {
+    LB_CHECK(hipMalloc(&out->nodes, sizeof(BvhNode) * (size_t)base));
+    LB_CHECK(hipMemcpyAsync(out->nodes, nodes_tmp, sizeof(BvhNode) * (size_t)base, hipMemcpyDeviceToDevice, s));
+  }
+  LB_CHECK(hipGetLastError());
+  LB_CHECK(hipStreamSynchronize(s));
+  out->root_ref = tlas.root_ref;
+  out->node_count = base;
+  out->depth4 = tlas.depth4 + deepest_blas;
+
+done:
+  (void)hipFree(tri_boxes); (void)hipFree(inst_boxes); (void)hipFree(mesh_boxes); (void)hipFree(nodes_tmp);
+  if (err != hipSuccess) {
+    (void)hipFree(out->nodes); (void)hipFree(out->tris); (void)hipFree(out->mesh_trav);
+    *out = LbvhResult{};
+  }
+  return err;
+}
+
 }  // namespace pt

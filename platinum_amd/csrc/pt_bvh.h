@@ -114,6 +114,11 @@ struct TravState {
   uint32_t cur;    // node to visit next
   float payload;   // the `ir` sample handed to the alpha-test intersection function (kernel.metal:510, 625)
   TraversalStack st;
+  // ---- two-level traversal only (dead in the one-BVH kernels): the ray in the space of the structure being walked ----
+  vec3 co, cinv;          // origin and reciprocal direction there (== o, inv while in the TLAS); t is the same parameter in both spaces
+  bool cnegx, cnegy, cnegz;
+  float sx, sy, sz;       // slab slack in t per axis: (object-space position error bound of this ray in this instance) * |cinv|
+  uint32_t tri_base;      // flattened index of the instance's first triangle: added to the BLAS leaf refs that are queued
 };
 
 // intersections.metal:8-39 alphaTestIntersectionFunction: runs for every candidate hit on a non-opaque instance;
@@ -171,6 +176,10 @@ PT_HD bool trav_init(const DeviceScene& S, TravState& ts, vec3 o, vec3 d, float 
   ts.st.sp = 0;
   ts.st.npend = 0;
   ts.cur = S.root_ref;
+  ts.co = ts.o; ts.cinv = ts.inv;
+  ts.cnegx = ts.negx; ts.cnegy = ts.negy; ts.cnegz = ts.negz;
+  ts.sx = ts.sy = ts.sz = 0.0f;
+  ts.tri_base = 0u;
   if (S.root_ref == kInvalidRef) return true;
   if (S.root_ref & kLeafBit) {  // single-triangle scene
     bool fin = false;
@@ -255,31 +264,36 @@ PT_HD Box3 inflate_box(const Box3& b) {
 // they go to the lane's leaf queue, and the caller runs the triangle code when enough lanes of the wave have one queued
 // (measured before this split: the in-place triangle loop ran at 11 % lane utilisation on C2, 8 % on C3).
 // On return ts.cur is the next node, or kInvalidRef when the node stack is exhausted.
-template <bool COUNT>
-PT_HD void trav_node(const DeviceScene& S, TravState& ts, TraversalCount* cnt) {
-  const BvhNode n = S.nodes[ts.cur];
+template <bool COUNT, bool TWO = false>
+PT_HD void trav_node(const BvhNode* __restrict__ nodes, TravState& ts, TraversalCount* cnt) {
+  const BvhNode n = nodes[ts.cur];
   if (COUNT) cnt->nodes++;
-  const float ax = node_scale(n.exp[0]) * ts.inv.x, ay = node_scale(n.exp[1]) * ts.inv.y, az = node_scale(n.exp[2]) * ts.inv.z;
-  const float bx = (n.origin[0] - ts.o.x) * ts.inv.x, by = (n.origin[1] - ts.o.y) * ts.inv.y, bz = (n.origin[2] - ts.o.z) * ts.inv.z;
+  const vec3 ro = TWO ? ts.co : ts.o, ri = TWO ? ts.cinv : ts.inv;
+  const bool gx = TWO ? ts.cnegx : ts.negx, gy = TWO ? ts.cnegy : ts.negy, gz = TWO ? ts.cnegz : ts.negz;
+  const float ax = node_scale(n.exp[0]) * ri.x, ay = node_scale(n.exp[1]) * ri.y, az = node_scale(n.exp[2]) * ri.z;
+  const float bx = (n.origin[0] - ro.x) * ri.x, by = (n.origin[1] - ro.y) * ri.y, bz = (n.origin[2] - ro.z) * ri.z;
+  // two-level: the object-space ray carries a rounding error; every slab is widened by its bound (zero while in the TLAS)
+  const float bnx = TWO ? bx - ts.sx : bx, bny = TWO ? by - ts.sy : by, bnz = TWO ? bz - ts.sz : bz;
+  const float bfx = TWO ? bx + ts.sx : bx, bfy = TWO ? by + ts.sy : by, bfz = TWO ? bz + ts.sz : bz;
   // entry / exit planes per axis by direction sign (one select per dword instead of a min/max pair per child)
-  const uint32_t nx = ts.negx ? n.qhi[0] : n.qlo[0], fx = ts.negx ? n.qlo[0] : n.qhi[0];
-  const uint32_t ny = ts.negy ? n.qhi[1] : n.qlo[1], fy = ts.negy ? n.qlo[1] : n.qhi[1];
-  const uint32_t nz = ts.negz ? n.qhi[2] : n.qlo[2], fz = ts.negz ? n.qlo[2] : n.qhi[2];
+  const uint32_t nx = gx ? n.qhi[0] : n.qlo[0], fx = gx ? n.qlo[0] : n.qhi[0];
+  const uint32_t ny = gy ? n.qhi[1] : n.qlo[1], fy = gy ? n.qlo[1] : n.qhi[1];
+  const uint32_t nz = gz ? n.qhi[2] : n.qlo[2], fz = gz ? n.qlo[2] : n.qhi[2];
   float dist[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     // (fused multiply-adds: this arithmetic only has to be conservative, not reproducible — a NaN from 0 * inf is
     //  dropped by fmax/fmin, which widens the box)
-    const float tnx = __builtin_fmaf((float)((nx >> (8 * k)) & 0xffu), ax, bx), tfx = __builtin_fmaf((float)((fx >> (8 * k)) & 0xffu), ax, bx);
-    const float tny = __builtin_fmaf((float)((ny >> (8 * k)) & 0xffu), ay, by), tfy = __builtin_fmaf((float)((fy >> (8 * k)) & 0xffu), ay, by);
-    const float tnz = __builtin_fmaf((float)((nz >> (8 * k)) & 0xffu), az, bz), tfz = __builtin_fmaf((float)((fz >> (8 * k)) & 0xffu), az, bz);
+    const float tnx = __builtin_fmaf((float)((nx >> (8 * k)) & 0xffu), ax, bnx), tfx = __builtin_fmaf((float)((fx >> (8 * k)) & 0xffu), ax, bfx);
+    const float tny = __builtin_fmaf((float)((ny >> (8 * k)) & 0xffu), ay, bny), tfy = __builtin_fmaf((float)((fy >> (8 * k)) & 0xffu), ay, bfy);
+    const float tnz = __builtin_fmaf((float)((nz >> (8 * k)) & 0xffu), az, bnz), tfz = __builtin_fmaf((float)((fz >> (8 * k)) & 0xffu), az, bfz);
     const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), ts.tmin);
     const float tf = fminf(fminf(fminf(tfx, tfy), tfz), ts.best.t);
     const bool hit = n.ref[k] != kInvalidRef && tn <= __builtin_fmaf(tf, 1.0000005f, 1e-30f);
     const bool leaf = hit && (n.ref[k] & kLeafBit);
-    dist[k] = hit && !leaf ? tn : kInf;  // leaves never go on the node stack
-    // queue the leaf (branch-free: a non-leaf writes to the scratch row kPendLeaves)
-    ts.st.pend[(leaf ? ts.st.npend : kPendLeaves) * ts.st.lds_stride] = n.ref[k];
+    dist[k] = hit && !leaf ? tn : kInf;  // leaves never go on the node stack (TLAS leaves — kInstBit — do: they are entered like nodes)
+    // queue the leaf (branch-free: a non-leaf writes to the scratch row kPendLeaves); two-level: as the flattened triangle
+    ts.st.pend[(leaf ? ts.st.npend : kPendLeaves) * ts.st.lds_stride] = TWO ? n.ref[k] + ts.tri_base : n.ref[k];
     ts.st.npend += leaf ? 1 : 0;
   }
   // internal children: nearest becomes `cur`, the others are pushed far-to-near
@@ -302,6 +316,71 @@ PT_HD void trav_node(const DeviceScene& S, TravState& ts, TraversalCount* cnt) {
   }
 }
 
+// ---- two-level traversal: entering and leaving an instance ------------------------------------------------------------
+// Called when ts.cur is not a plain node: an exit marker (back to world space) or a TLAS leaf (kInstBit | instance).
+// Entering takes the ray to the instance's object space for the BLAS slab tests: co = M^-1 (o - c), cd = M^-1 d, the SAME
+// t.  Those are rounded values; the distance between the computed object-space ray and the exact one at parameter t is at
+// most ~4 ulp of sum_j |M^-1_ij| (|o_j - c_j| + t |d_j|).  The BLAS slabs are widened by e = 8e-6 * that sum at the far end
+// of the instance's bounds (the same relative margin the world-space boxes carry, 30x the rounding bound), so the walk still
+// reaches a superset of the triangles the WORLD-space Moeller-Trumbore test can accept: closest hits do not depend on which
+// structure was walked.  Needs room for one leaf in the lane's queue (a one-triangle mesh has no nodes).
+// trav_leave: the cheap half (exit markers) — run by every lane as soon as one comes up.
+PT_HD void trav_leave(TravState& ts) {
+  while (ts.cur == kExitMarker) {
+    ts.co = ts.o; ts.cinv = ts.inv;
+    ts.cnegx = ts.negx; ts.cnegy = ts.negy; ts.cnegz = ts.negz;
+    ts.sx = ts.sy = ts.sz = 0.0f;
+    ts.tri_base = 0u;
+    ts.cur = ts.st.sp == 0 ? kInvalidRef : ts.st.pop();
+  }
+}
+PT_HD void trav_resolve(const DeviceScene& S, TravState& ts) {
+  for (;;) {
+    if (ts.cur == kExitMarker) {
+      ts.co = ts.o; ts.cinv = ts.inv;
+      ts.cnegx = ts.negx; ts.cnegy = ts.negy; ts.cnegz = ts.negz;
+      ts.sx = ts.sy = ts.sz = 0.0f;
+      ts.tri_base = 0u;
+      ts.cur = ts.st.sp == 0 ? kInvalidRef : ts.st.pop();
+      continue;
+    }
+    if (ts.cur == kInvalidRef || !(ts.cur & kInstBit)) return;
+    if (ts.st.npend > kPendLeaves - 4) return;  // (no room in the leaf queue: the caller runs a triangle round first)
+    const InstanceTrav it = ldg(&S.inst_trav[ts.cur & ~kInstBit]);
+    const MeshTrav mt = ldg(&S.mesh_trav[it.mesh]);
+    if (mt.root_ref == kInvalidRef || (mt.root_ref & kLeafBit)) {
+      // a mesh without triangles, or with one: that one is the candidate (no nodes to walk, the ray stays where it is)
+      if (mt.root_ref != kInvalidRef) ts.st.push_leaf(kLeafBit | (it.tri_base + (mt.root_ref & ~kLeafBit)));
+      ts.cur = ts.st.sp == 0 ? kInvalidRef : ts.st.pop();
+      continue;
+    }
+    const vec3 p = ts.o - v3(it.c[0], it.c[1], it.c[2]);
+    const vec3 i0 = v3(it.ic0[0], it.ic0[1], it.ic0[2]), i1 = v3(it.ic1[0], it.ic1[1], it.ic1[2]), i2 = v3(it.ic2[0], it.ic2[1], it.ic2[2]);
+    ts.co = (i0 * p.x + i1 * p.y) + i2 * p.z;
+    const vec3 cd = (i0 * ts.d.x + i1 * ts.d.y) + i2 * ts.d.z;
+    ts.cinv = v3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
+    if (!(fabsf(ts.cinv.x) <= 1e30f)) ts.cinv.x = copysignf(1e30f, cd.x);
+    if (!(fabsf(ts.cinv.y) <= 1e30f)) ts.cinv.y = copysignf(1e30f, cd.y);
+    if (!(fabsf(ts.cinv.z) <= 1e30f)) ts.cinv.z = copysignf(1e30f, cd.z);
+    ts.cnegx = ts.cinv.x < 0.0f; ts.cnegy = ts.cinv.y < 0.0f; ts.cnegz = ts.cinv.z < 0.0f;
+    // where the ray leaves the mesh's bounds (the largest t any hit in this instance can have)
+    const float fx = ((ts.cnegx ? mt.lo[0] : mt.hi[0]) - ts.co.x) * ts.cinv.x;
+    const float fy = ((ts.cnegy ? mt.lo[1] : mt.hi[1]) - ts.co.y) * ts.cinv.y;
+    const float fz = ((ts.cnegz ? mt.lo[2] : mt.hi[2]) - ts.co.z) * ts.cinv.z;
+    const float t1 = fminf(fminf(fx, fy), fz);
+    const float tfar = fminf(ts.best.t, fmaxf(t1, 0.0f) * 1.0001f + 1e-6f);
+    const vec3 ap = v3(fabsf(p.x), fabsf(p.y), fabsf(p.z)), ad = v3(fabsf(ts.d.x), fabsf(ts.d.y), fabsf(ts.d.z));
+    const vec3 a0 = v3(fabsf(i0.x), fabsf(i0.y), fabsf(i0.z)), a1 = v3(fabsf(i1.x), fabsf(i1.y), fabsf(i1.z)), a2 = v3(fabsf(i2.x), fabsf(i2.y), fabsf(i2.z));
+    const vec3 mp = (a0 * ap.x + a1 * ap.y) + a2 * ap.z, md = (a0 * ad.x + a1 * ad.y) + a2 * ad.z;
+    float e = 8e-6f * (fmaxf(mp.x, fmaxf(mp.y, mp.z)) + tfar * fmaxf(md.x, fmaxf(md.y, md.z))) + 1e-30f;
+    if (!(e <= 1e30f)) e = 1e30f;
+    ts.sx = e * fabsf(ts.cinv.x); ts.sy = e * fabsf(ts.cinv.y); ts.sz = e * fabsf(ts.cinv.z);
+    ts.tri_base = it.tri_base;
+    ts.st.push(kExitMarker);
+    ts.cur = mt.root_ref;
+  }
+}
+
 // Tests one queued leaf.  Returns true when an any-hit ray is finished by it.
 template <bool ANY, bool COUNT>
 PT_HD bool trav_pending_leaf(const DeviceScene& S, TravState& ts, TraversalCount* cnt) {
@@ -314,7 +393,7 @@ PT_HD bool trav_pending_leaf(const DeviceScene& S, TravState& ts, TraversalCount
 // scheduling in kernels.hip — the answer does not depend on the order in which candidates are tested).
 template <bool ANY, bool COUNT>
 PT_HD bool trav_step(const DeviceScene& S, TravState& ts, TraversalCount* cnt) {
-  trav_node<COUNT>(S, ts, cnt);
+  trav_node<COUNT>(S.nodes, ts, cnt);
   while (ts.st.npend > 0)
     if (trav_pending_leaf<ANY, COUNT>(S, ts, cnt)) return true;
   return ts.cur == kInvalidRef;

@@ -86,6 +86,26 @@ static_assert(sizeof(BvhNode) == 64, "BvhNode");
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kInvalidRef = 0xffffffffu;
 
+// ---- two-level structure (instanced scenes; replaces the reference's BLAS per mesh + TLAS over instances,
+//      renderer_pt.cpp:653-749, for scenes that repeat a mesh many times) --------------------------------------------
+// One node array holds the TLAS (over the world boxes of the instances) followed by one BLAS per mesh (object space).
+// TLAS leaves are child refs `kInstBit | instance`: they are ordered and stacked like inner nodes and ENTERED when they
+// come up (the ray is taken to object space for the slab tests; kExitMarker on the stack brings it back).  BLAS leaves are
+// `kLeafBit | primitive`; the candidate that goes to the triangle queue is the flattened triangle `tri_base + primitive`,
+// and the triangle test itself stays the world-space one (tris[] in flattening order), so hits do not change by a bit.
+constexpr uint32_t kInstBit = 0x40000000u;
+constexpr uint32_t kExitMarker = 0xfffffffeu;
+struct alignas(16) InstanceTrav {  // 64 B: what entering an instance needs
+  float ic0[3], ic1[3], ic2[3];    // columns of the inverse of the instance's 3x3 (computed in double, rounded once)
+  float c[3];                      // its translation column
+  uint32_t tri_base;               // InstanceInfo::tri_global_base
+  uint32_t mesh;                   // index into mesh_trav[]
+  uint32_t _pad[2];
+};
+static_assert(sizeof(InstanceTrav) == 64, "InstanceTrav");
+struct alignas(16) MeshTrav { uint32_t root_ref, _pad; float lo[3], hi[3]; };  // 32 B: BLAS root, object-space bounds
+static_assert(sizeof(MeshTrav) == 32, "MeshTrav");
+
 // ---- sampler table: one entry per Halton dimension (defs.metal:115-194 holds the 620 primes) ---------------------
 // 32-bit integer multiplies are quarter rate on CDNA, so the radical inverse peels `digits` base-`prime` digits per
 // division by chunk = prime^digits (< 2^16) and splits the < 2^16 remainder with exact fp32 arithmetic.  The division
@@ -129,6 +149,10 @@ struct DeviceScene {
   const ShadeRec* shade_recs;  // tri_count records, same order as tris[]
   uint32_t tri_count;
   uint32_t root_ref;       // kLeafBit|0 for a single-triangle scene, the root's node index otherwise, kInvalidRef when empty
+  const InstanceTrav* inst_trav;  // two-level structure only (two_level != 0): root_ref is the TLAS root, tris[] is in flattening order
+  const MeshTrav* mesh_trav;
+  uint32_t two_level;
+  uint32_t node_count;     // records in nodes[] (a small two-level structure is staged in LDS by the trace kernels)
   const HaltonEntry* halton;
   LutSet luts;
   const vec4* tex_pixels;

@@ -179,6 +179,7 @@ int dev_create(const pt_create_info* info, int device_ordinal, pt_renderer** out
   if (const char* e = getenv("PTAMD_REFILL")) r->refill_threshold = (uint32_t)atoi(e);
   if (const char* e = getenv("PTAMD_TILES_PER_SEG")) r->tiles_per_seg_override = (uint32_t)std::max(0, atoi(e));  // tuning knobs
   if (const char* e = getenv("PTAMD_SEG_BANDS")) r->seg_bands = (uint32_t)std::max(1, std::min(64, atoi(e)));
+  if (const char* e = getenv("PTAMD_TWO_LEVEL")) r->two_level_override = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("PTAMD_BLOCKS_PER_CU")) r->blocks_per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));
   if (const char* e = getenv("PTAMD_TRACE_BLOCKS_PER_CU")) r->trace_blocks_per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));
   hipDeviceProp_t prop;
@@ -231,6 +232,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   if ((uint64_t)p->width * p->height > (1ull << 28)) return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: image too large");
   if (p->integrator != PT_INTEGRATOR_SIMPLE && p->integrator != PT_INTEGRATOR_MIS) return fail(PT_ERR_INVALID_ARGUMENT, "bad integrator");
   if (p->nonfinite_policy > PT_NONFINITE_ZERO) return fail(PT_ERR_INVALID_ARGUMENT, "bad nonfinite_policy");
+  if (p->accel_structure > PT_ACCEL_TWO_LEVEL) return fail(PT_ERR_INVALID_ARGUMENT, "bad accel_structure");
   if ((p->flags & PT_FLAG_GMON) && (p->gmon_buckets < 1 || p->gmon_buckets > 32))
     return fail(PT_ERR_INVALID_ARGUMENT, "gmon_buckets must be 1..32 (gmon.metal:12 maxBuckets)");
   if (scene->instance_count && (!scene->instances || !scene->instance_materials || !scene->meshes))
@@ -303,7 +305,48 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
     PT_HIP(hipEventCreate(&ev.e0));
     PT_HIP(hipEventCreate(&ev.e1));
     PT_HIP(hipEventRecord(ev.e0, r->stream));
-    hipError_t be = build_lbvh(r->stream, S, r->instance_count, r->tri_count, (uint32_t)(kLdsStack + kSpillStack), &r->bvh);
+    // One BVH over the flattened triangles (fewest node visits per ray) unless the scene repeats its meshes so often that the
+    // two-level structure — TLAS over instances + one BLAS per mesh, small enough to sit in LDS — is the better trade
+    // (renderer_pt.cpp:653-749 always builds the two-level one).  Every instance must be invertible for that.
+    uint64_t unique_tris = 0;
+    for (const MeshInfo& m : hs.meshes) unique_tris += m.tri_count;
+    std::vector<InstanceTrav> itrav(hs.instances.size());
+    bool invertible = true;
+    for (size_t i = 0; i < hs.instances.size(); i++) {
+      const InstanceInfo& in = hs.instances[i];
+      M3d m{};
+      for (int k = 0; k < 3; k++) { m.m[0][k] = in.c0[k]; m.m[1][k] = in.c1[k]; m.m[2][k] = in.c2[k]; }
+      const double det = m.m[0][0] * (m.m[1][1] * m.m[2][2] - m.m[2][1] * m.m[1][2]) - m.m[1][0] * (m.m[0][1] * m.m[2][2] - m.m[2][1] * m.m[0][2]) +
+                         m.m[2][0] * (m.m[0][1] * m.m[1][2] - m.m[1][1] * m.m[0][2]);
+      double scale = 0;
+      for (int c = 0; c < 3; c++) for (int k = 0; k < 3; k++) scale = std::max(scale, std::fabs(m.m[c][k]));
+      if (!(std::fabs(det) > 1e-12 * scale * scale * scale) || !std::isfinite(det)) { invertible = false; break; }
+      const M3d inv = m3_inv(m);
+      InstanceTrav& t = itrav[i];
+      for (int k = 0; k < 3; k++) { t.ic0[k] = (float)inv.m[0][k]; t.ic1[k] = (float)inv.m[1][k]; t.ic2[k] = (float)inv.m[2][k]; t.c[k] = in.c3[k]; }
+      t.tri_base = in.tri_global_base; t.mesh = in.mesh; t._pad[0] = t._pad[1] = 0;
+    }
+    // Measured on C3 (1024 instances of a 1012-triangle mesh, MI355X): the two-level walk costs 1.75x the time of the one-BVH
+    // walk per ray (same 17.7 node visits, plus the instance entries) while its structure is 65 KB instead of 82 MB and reads
+    // a fraction of the bytes.  Rays per second is what this renderer is for, so one BVH is the default and the two-level
+    // structure is chosen when flattening would not leave room for the path queues (or on request, $PTAMD_TWO_LEVEL=1).
+    {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+      const uint64_t flat_bytes = (uint64_t)r->tri_count * 260ull;  // TriRec + nodes + ShadeRec + the builder's scratch at its peak
+      r->two_level = invertible && (uint64_t)r->tri_count >= 8 * unique_tris && free_b != 0 && flat_bytes > free_b / 2;
+    }
+    if (p->accel_structure == PT_ACCEL_ONE_BVH) r->two_level = false;
+    else if (p->accel_structure == PT_ACCEL_TWO_LEVEL) r->two_level = invertible;
+    else if (r->two_level_override >= 0) r->two_level = invertible && r->two_level_override != 0;
+    hipError_t be;
+    if (r->two_level) {
+      PT_HIP(r->inst_trav.upload(itrav));
+      be = build_two_level(r->stream, S, hs.meshes.data(), (uint32_t)hs.meshes.size(), r->instance_count, r->tri_count,
+                           (uint32_t)(kLdsStack + kSpillStack), &r->bvh);
+    } else {
+      be = build_lbvh(r->stream, S, r->instance_count, r->tri_count, (uint32_t)(kLdsStack + kSpillStack), &r->bvh);
+    }
     if (be != hipSuccess)
       return fail(be == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP, std::string("LBVH build failed: ") + hipGetErrorString(be));
     PT_HIP(hipEventRecord(ev.e1, r->stream));
@@ -312,11 +355,15 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
     (void)hipEventElapsedTime(&ms, ev.e0, ev.e1);
     r->bvh_ms = ms;
     // traversal stack: <= 3 pushes per 4-wide level; 4-wide depth = ceil(binary depth / 2)
-    if (r->bvh.depth4 * 3 > (uint32_t)(kLdsStack + kSpillStack))
+    if (r->bvh.depth4 * 3 + (r->two_level ? 1 : 0) > (uint32_t)(kLdsStack + kSpillStack))
       return fail(PT_ERR_UNSUPPORTED, "BVH too deep for the traversal stack (degenerate geometry: thousands of coincident triangles?)");
     S.nodes = r->bvh.nodes;
     S.tris = r->bvh.tris;
     S.root_ref = r->bvh.root_ref;
+    S.node_count = r->bvh.node_count;
+    S.two_level = r->two_level ? 1u : 0u;
+    S.inst_trav = r->inst_trav.p;
+    S.mesh_trav = r->bvh.mesh_trav;
   }
   PT_HIP(r->shade_recs.alloc(r->tri_count));
   S.shade_recs = r->shade_recs.p;
@@ -341,7 +388,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   // segments round-robin; the trace kernels claim chunks from a table, so every grid is sized for its own kernel's occupancy.
   r->grid = (uint32_t)r->num_cu * r->blocks_per_cu;                 // raygen, hit records: 256-thread blocks
   r->shade_grid = (uint32_t)r->num_cu * shade_blocks_per_cu();     // as many blocks as k_shade's registers / LDS keep resident
-  r->trace_grid = (uint32_t)r->num_cu * r->trace_blocks_per_cu;
+  r->trace_grid = r->two_level ? (uint32_t)r->num_cu * trace_blocks_per_cu_two_level() : (uint32_t)r->num_cu * r->trace_blocks_per_cu;
   {
     const uint64_t tiles = (uint64_t)((p->width + 7) / 8) * ((p->height + 7) / 8);
     r->tiles_per_seg = (uint32_t)((tiles + 32639) / 32640);  // nseg <= 32768 after rounding up to a multiple of the band count
@@ -364,7 +411,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   PT_HIP(r->seg_shadow.alloc(r->nseg));
   PT_HIP(r->wave_stats.alloc(r->nstats));
   for (int k = 0; k < 2; k++) PT_HIP(r->chunk_table[k].alloc(r->capacity / 64));
-  PT_HIP(r->spill.alloc((size_t)r->trace_grid * kBlock * kSpillStack));  // per-thread HBM stack slab behind the LDS stack
+  PT_HIP(r->spill.alloc((size_t)r->trace_grid * trace_block_threads(r->two_level) * kSpillStack));  // per-thread HBM stack slab behind the LDS stack
   PT_HIP(hipMemsetAsync(r->wave_stats.p, 0, sizeof(WaveStats) * r->nstats, r->stream));
   if (p->external_accumulator) {
     r->acc = (vec4*)p->external_accumulator;
@@ -635,6 +682,7 @@ int dev_get_stats(pt_renderer* r, pt_stats* out) {
   out->nonfinite_samples = t.nonfinite;
   out->ms_raygen = r->ms_class[K_RAYGEN]; out->ms_closest = r->ms_class[K_CLOSEST]; out->ms_shade = r->ms_class[K_SHADE];
   out->ms_shadow = r->ms_class[K_SHADOW]; out->ms_accumulate = r->ms_class[K_ACCUM];
+  out->accel_two_level = r->two_level ? 1u : 0u;
   out->launches_closest = r->launches[K_CLOSEST];
   out->launches_shadow = r->launches[K_SHADOW];
   if (t.counted_closest) {

@@ -83,6 +83,9 @@ struct pt_renderer {
   std::vector<pt_area_light> lights;
   DevBuf<DeviceScene> scene_d;
   DevBuf<ShadeRec> shade_recs;
+  DevBuf<InstanceTrav> inst_trav;   // two-level structure only
+  bool two_level = false;
+  int two_level_override = -1;      // $PTAMD_TWO_LEVEL: 0 / 1 force the choice, -1 = by instancing factor
   DevBuf<vec4> tex_pixels;            // all textures decoded to linear float4 (host_scene.h decode_textures)
   DevBuf<TexInfo> textures;
   DevBuf<pt_alias_entry> env_alias_d;
@@ -140,6 +143,8 @@ struct pt_renderer {
     materials.release(); lights_d.release(); tex_pixels.release(); textures.release(); env_alias_d.release(); scene_d.release(); shade_recs.release();
     if (bvh.nodes) (void)hipFree(bvh.nodes);
     if (bvh.tris) (void)hipFree(bvh.tris);
+    if (bvh.mesh_trav) (void)hipFree(bvh.mesh_trav);
+    inst_trav.release();
     bvh = LbvhResult{};
     for (int k = 0; k < 2; k++) { st_rayO[k].release(); st_rayD[k].release(); st_att[k].release(); st_pid[k].release(); }
     seg_active[0].release(); seg_active[1].release(); seg_shadow.release(); wave_stats.release(); chunk_table[0].release(); chunk_table[1].release(); gmon_buckets_d.release(); render_target.release();

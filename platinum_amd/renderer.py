@@ -13,8 +13,9 @@ from . import abi, scenes
 
 def make_params(width, height, spp, max_bounces, flags=abi.FLAG_MULTISCATTER_GGX, integrator=abi.INTEGRATOR_MIS,
                 working_space=scenes.BT2020, gmon_buckets=1, first_sample=0, samples_in_flight=0,
-                external_accumulator=None, stream=None, nonfinite_policy=abi.NONFINITE_PROPAGATE):
+                external_accumulator=None, stream=None, nonfinite_policy=abi.NONFINITE_PROPAGATE, accel_structure=abi.ACCEL_AUTO):
     p = abi.RenderParams()
+    p.accel_structure = accel_structure
     p.width, p.height, p.spp, p.gmon_buckets = width, height, spp, gmon_buckets
     p.flags, p.integrator = flags, integrator
     p.working_space = scenes.colorspace(working_space)
@@ -70,11 +71,11 @@ class Renderer:
 
     def startRender(self, scene, size, spp, gmonBuckets=1, workingSpace=scenes.BT2020, flags=abi.FLAG_MULTISCATTER_GGX,
                     max_bounces=50, first_sample=0, samples_in_flight=0, external_accumulator=None, stream=None,
-                    nonfinite_policy=abi.NONFINITE_PROPAGATE):
+                    nonfinite_policy=abi.NONFINITE_PROPAGATE, accel_structure=abi.ACCEL_AUTO):
         """startRender(camera, size, spp, gmonBuckets, workingSpace, flags) (renderer_pt.hpp:38-45).
         `scene` (a scenes.Scene holding the camera node) replaces the NodeID into Store."""
         p = make_params(int(size[0]), int(size[1]), spp, max_bounces, flags, self._integrator, workingSpace, gmonBuckets,
-                        first_sample, samples_in_flight, external_accumulator, stream, nonfinite_policy)
+                        first_sample, samples_in_flight, external_accumulator, stream, nonfinite_policy, accel_structure)
         snap = scene.snapshot()
         abi.check(self._lib, self._lib.pt_start_render(self._h, C.byref(snap.struct), C.byref(p)))
         self._params = p
