@@ -325,6 +325,11 @@ int pt_set_tonemap_options(pt_renderer* r, const pt_tonemap_options* o);
 /* readbackRenderTarget() (renderer_pt.hpp:57, renderer_pt.cpp:1039-1059): the post-processed, tonemapped RGBA8 image
  * (W*H*4 bytes, row-major, top-left origin). Blocks. */
 int pt_read_render_target(pt_renderer* r, uint8_t* rgba8_out);
+/* presentRenderTarget() (renderer_pt.hpp:55, used by pt_viewport.cpp:711 to blit): post-processes the current accumulator into
+ * the library's RGBA8 render target ON THE DEVICE and returns its device address (W*H*4 bytes, valid until the next
+ * pt_start_render / pt_destroy) without a host copy.  The work is enqueued on the renderer's stream; *stream_out (may be NULL)
+ * receives that hipStream_t so the caller can order its blit after it.  A device group presents on device_ordinals[0]. */
+int pt_present_render_target(pt_renderer* r, void** device_rgba8_out, void** stream_out);
 
 /* The float accumulator: W*H RGBA32F, row-major, top-left origin, running mean, alpha 1
  * (renderer_pt.cpp:812-821, kernel.metal:672-684).  Blocks like readbackRenderTarget (:1039-1059). */

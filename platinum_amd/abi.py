@@ -204,6 +204,7 @@ SYMBOLS = [
     ("pt_set_post_options", C.c_int, [C.c_void_p, C.POINTER(PostOptions)]),
     ("pt_set_tonemap_options", C.c_int, [C.c_void_p, C.POINTER(TonemapOptions)]),
     ("pt_read_render_target", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("pt_present_render_target", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("pt_read_gmon_bucket", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     ("pt_last_error", C.c_char_p, []),
     ("pt_get_constants", C.c_int, [C.c_void_p, C.POINTER(Constants)]),

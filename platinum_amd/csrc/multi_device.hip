@@ -507,6 +507,17 @@ int pt_read_render_target(pt_renderer* r, uint8_t* rgba8_out) {
   return dev_postprocess_to_host(m, grp->merged, rgba8_out);
 }
 
+int pt_present_render_target(pt_renderer* r, void** device_rgba8_out, void** stream_out) {
+  if (!is_group(r)) return dev_present(r, nullptr, device_rgba8_out, stream_out);
+  DeviceGroup* grp = r->group;
+  if (!grp->started) return fail(PT_ERR_BAD_STATE, "pt_present_render_target before pt_start_render");
+  int rc = group_wait(r);  // merges the members' accumulators
+  if (rc != PT_OK) return rc;
+  pt_renderer* m = first_started(grp);
+  if (!m || m->device != grp->shards[0]->device) return fail(PT_ERR_BAD_STATE, "device group: no member on the first device has samples");
+  return dev_present(m, grp->merged, device_rgba8_out, stream_out);
+}
+
 int pt_set_gmon_options(pt_renderer* r, const pt_gmon_options* o) {
   if (!is_group(r)) return dev_set_gmon_options(r, o);
   for (auto* m : r->group->shards) { int rc = dev_set_gmon_options(m, o); if (rc != PT_OK) return rc; }

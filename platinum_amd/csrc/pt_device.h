@@ -108,12 +108,13 @@ static_assert(sizeof(MeshTrav) == 32, "MeshTrav");
 
 // ---- sampler table: one entry per Halton dimension (defs.metal:115-194 holds the 620 primes) ---------------------
 // 32-bit integer multiplies are quarter rate on CDNA, so the radical inverse peels `digits` base-`prime` digits per
-// division by chunk = prime^digits (< 2^16) and splits the < 2^16 remainder with exact fp32 arithmetic.  The division
-// is the round-up multiply-shift of Granlund & Montgomery with a 33-bit multiplier 2^32 + magic, l = ceil(log2 chunk):
+// division by chunk = prime^digits (the largest power below 2^22: two divisions cover a 32-bit index for every prime up to
+// 2047, three beyond) and splits the remainder with exact fp32 arithmetic.  The division is the round-up multiply-shift of
+// Granlund & Montgomery with a 33-bit multiplier 2^32 + magic, l = ceil(log2 chunk):
 //   t = mulhi(magic, n);  q = (t + ((n - t) >> 1)) >> (l - 1)          exact for every 32-bit n
-// — ONE quarter-rate multiply per chunk (q * chunk is a 24-bit multiply: q < 2^24 because chunk >= 257).
+// — ONE quarter-rate multiply per chunk (q * chunk is a 24-bit multiply: q < 2^24 because chunk >= 257, chunk < 2^22).
 struct alignas(16) HaltonEntry {
-  uint32_t chunk;    // prime^digits, 257 <= chunk < 2^16
+  uint32_t chunk;    // prime^digits, 257 <= chunk < 2^22
   uint32_t magic;    // floor(2^32 * (2^l - chunk) / chunk) + 1
   uint32_t shift;    // l - 1
   float inv;         // 1.0f / (float)prime  (the reference's invB, samplers.metal:172)

@@ -39,7 +39,7 @@ PT_HD uint32_t halton_offset(uint32_t px, uint32_t py, uint32_t sample) { return
 inline HaltonEntry make_halton_entry(uint32_t prime) {
   uint32_t digits = 1;
   uint64_t chunk = prime;
-  while (chunk * prime < 65536ull) { chunk *= prime; digits++; }
+  while (chunk * prime < (1ull << 22)) { chunk *= prime; digits++; }  // chunk < 2^22: see HaltonEntry
   uint32_t l = 0;
   while ((1ull << l) < chunk) l++;  // l = ceil(log2 chunk)
   const uint64_t magic = ((1ull << 32) * ((1ull << l) - chunk)) / chunk + 1;  // < 2^32
@@ -67,12 +67,13 @@ PT_HD float halton(const HaltonTab& tab, uint32_t i, uint32_t d) {
     // q = i / chunk (HaltonEntry); rem = i % chunk holds `digits` base-prime digits
     const uint32_t t = mulhi_u32(e.magic, i);
     const uint32_t q = (t + ((i - t) >> 1)) >> e.shift;
-    float rem = (float)(i - mul_u24(q, e.chunk));  // < 2^16: exact
+    float rem = (float)(i - mul_u24(q, e.chunk));  // < 2^22: exact
     if (e.digits == 1) {
       f = f * e.inv;
       r = r + f * rem;
     } else {
-      // rem / prime for rem < 2^16: floor((rem + 0.5) * inv) is exact (|error| <= 2^-7 / prime < 0.5 / prime).
+      // rem / prime for rem < 2^22: floor((rem + 0.5) * inv) is exact — (rem + 0.5) / prime is at least 0.5 / prime away from
+      // an integer and the two roundings (inv, the product) move it by at most (rem / prime) * 2^-23 < 0.5 / prime.
       // Leading zero digits of the last chunk add f * 0 = 0 to r, exactly like not visiting them.
       for (uint32_t j = 0; j < e.digits; j++) {
         const float qf = floorf((rem + 0.5f) * e.inv);

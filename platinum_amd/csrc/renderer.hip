@@ -549,6 +549,25 @@ int dev_postprocess_to_host(pt_renderer* r, const vec4* acc_device, uint8_t* rgb
   return PT_OK;
 }
 
+// the device half of dev_postprocess_to_host: enqueue only
+int dev_present(pt_renderer* r, const vec4* acc_device, void** device_rgba8_out, void** stream_out) {
+  if (!r || !device_rgba8_out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!r->started) return fail(PT_ERR_BAD_STATE, "pt_present_render_target before pt_start_render");
+  PT_HIP(hipSetDevice(r->device));
+  const size_t npix = (size_t)r->S.width * r->S.height;
+  if (r->render_target.n != npix) PT_HIP(r->render_target.alloc(npix));
+  PostConstants pc;
+  pc.post = r->post;
+  pc.tm = r->tonemap;
+  const Mat3 odt = compute_transform(r->params.working_space, r->tonemap.output_space);  // renderer_pt.cpp:190-191
+  pc.odt = PPMat3{odt.c0, odt.c1, odt.c2};
+  launch_postprocess(r->stream, acc_device ? acc_device : r->acc, r->render_target.p, r->S.width, r->S.height, pc);
+  PT_HIP(hipGetLastError());
+  *device_rgba8_out = r->render_target.p;
+  if (stream_out) *stream_out = (void*)r->stream;
+  return PT_OK;
+}
+
 int dev_read_render_target(pt_renderer* r, uint8_t* rgba8_out) {
   if (!r || !rgba8_out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   if (!r->started) return fail(PT_ERR_BAD_STATE, "pt_read_render_target before pt_start_render");

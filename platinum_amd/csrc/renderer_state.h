@@ -173,6 +173,7 @@ int dev_set_post_options(pt_renderer* r, const pt_post_options* o);
 int dev_set_tonemap_options(pt_renderer* r, const pt_tonemap_options* o);
 int dev_read_render_target(pt_renderer* r, uint8_t* rgba8_out);
 int dev_postprocess_to_host(pt_renderer* r, const vec4* acc_device, uint8_t* rgba8_out);  // the tail of read_render_target on a given image
+int dev_present(pt_renderer* r, const vec4* acc_device, void** device_rgba8_out, void** stream_out);  // enqueue only; acc_device NULL = own accumulator
 int dev_set_gmon_options(pt_renderer* r, const pt_gmon_options* o);
 int dev_read_gmon_bucket(pt_renderer* r, uint32_t bucket, float* rgba_out);
 void* dev_accumulator_device_ptr(pt_renderer* r);

@@ -129,6 +129,12 @@ class Renderer:
         abi.check(self._lib, self._lib.pt_read_render_target(self._h, out.ctypes.data))
         return out
 
+    def presentRenderTarget(self):
+        """presentRenderTarget() (renderer_pt.hpp:55): (device address of the RGBA8 image, hipStream_t it is produced on)."""
+        ptr, stream = C.c_void_p(), C.c_void_p()
+        abi.check(self._lib, self._lib.pt_present_render_target(self._h, C.byref(ptr), C.byref(stream)))
+        return ptr.value, stream.value
+
     def setGmonOptions(self, cap=1.0):
         """gmonOptions().cap (renderer_pt.hpp:71)."""
         o = abi.GmonOptions(cap)

@@ -192,6 +192,24 @@ def test_gmon_matches_oracle(gpu_renderer, spp, buckets, sif):
     gpu_renderer.setGmonOptions(cap=1.0)
 
 
+def test_present_render_target_is_the_readback_image_on_the_device(gpu_renderer):
+    """presentRenderTarget() (renderer_pt.hpp:55): the RGBA8 image stays in HBM; its bytes equal readbackRenderTarget()'s."""
+    torch = pytest.importorskip("torch")
+    sc = _scene("cornell_sphere")
+    w, h = 96, 64
+    _start(gpu_renderer, sc, w, h, 3, 5)
+    gpu_renderer.render(0)
+    gpu_renderer.wait()
+    ptr, stream = gpu_renderer.presentRenderTarget()
+    assert ptr and stream
+    want = gpu_renderer.readbackRenderTarget()      # (synchronises the renderer's stream)
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    got = np.empty((h, w, 4), np.uint8)
+    assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), C.c_void_p(ptr), C.c_size_t(got.nbytes), 2) == 0  # hipMemcpyDeviceToHost
+    assert np.array_equal(got, want) and want[..., 3].min() == 255
+
+
 def test_postprocess_tonemap_rgba8_matches_oracle(gpu_renderer):
     """exposure / CA / contrast-saturation / tone curve / vignette / tonemap / lift-gamma-gain / odt / sRGB
     -> RGBA8, identical to the oracle for the three tonemappers (at most 1 LSB on a handful of pixels is tolerated in

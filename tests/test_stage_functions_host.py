@@ -34,8 +34,8 @@ def test_magic_division_halton_equals_oracle():
     e = emu_lib.EmuScene(scenes.cornell_scene(), make_params(8, 8, 1, 2))
     L = oracle_lib.lib()
     rng = np.random.default_rng(11)
-    for i in [0, 1, 2, 0xFFFFFFFF, 0x80000000, 65535, 65536, 59049, 59048, 14641 * 14641 - 1] + [int(v) for v in rng.integers(0, 2**32, 300)]:
-        for d in (0, 1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 13, 52, 53, 54, 55, 256, 257, 619):  # every digits-per-chunk class
+    for i in [0, 1, 2, 0xFFFFFFFF, 0x80000000, 65535, 65536, 59049, 59048, 14641 * 14641 - 1] + [int(v) for v in rng.integers(0, 2**32, 1500)]:
+        for d in (0, 1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 13, 52, 53, 54, 55, 100, 256, 257, 302, 303, 619):  # every digits-per-chunk class
             assert e.halton(i, d) == L.orc_halton(i, d), (i, d)
 
 
@@ -77,9 +77,17 @@ def test_halton_fp32_division_boundaries_equal_oracle():
     for d in list(range(0, 64)) + list(range(64, 620, 7)) + [619]:
         p = L.orc_prime(d)
         chunk = p
-        while chunk * p < 65536:
+        while chunk * p < (1 << 22):   # pt_sampler.h make_halton_entry: the largest power below 2^22
             chunk *= p
-        ks = [1, 2, (1 << 21) // chunk - 1, (1 << 21) // chunk, (1 << 21) // chunk + 1, (1 << 32) // chunk - 1]
+        ks = [1, 2, 3, max(1, (1 << 21) // chunk - 1), max(1, (1 << 21) // chunk), (1 << 21) // chunk + 1, chunk - 1, chunk, chunk + 1,
+              (1 << 32) // chunk - 1, (1 << 32) // chunk]
+        # remainders whose digit splits sit on the fp32 rounding boundary: multiples of the prime (+-1) just below the chunk
+        rems = [chunk - 1, chunk - p, chunk - p - 1, chunk - p + 1, (chunk // p) * p - 1, p * (p - 1), p * p - 1 if p * p <= chunk else chunk - 1]
+        for r in rems:
+            for q in (0, 1, (1 << 32) // chunk - 1):
+                i = q * chunk + r
+                if 0 <= i < (1 << 32):
+                    assert e.halton(i, d) == L.orc_halton(i, d), (i, d)
         for k in ks:
             for i in (k * chunk - 1, k * chunk, k * chunk + 1):
                 if 0 <= i < (1 << 32):
