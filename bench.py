@@ -23,7 +23,7 @@ steps with HIP events around every launch (on the renderer's stream).  Rank 0 pr
   roofline_kernels  the same block for each hot kernel (k_shade, k_trace_closest, k_trace_shadow)
   cpu_baseline      (N = 1) the CPU oracle on the host cores, bounded sample of the same workload
 Ceilings (MI355X_MICROARCH.md): HBM 8.0 TB/s; L2 34.5 TB/s aggregate; VALU issue 256 CU x 4 SIMD x 32 lanes x 2.4 GHz =
-78.6 T lane-ops/s.  Algorithmic bytes follow SURVEY §8(d); counter-based bytes and VALU instruction counts per work item
+78.6 T lane-ops/s; and, measured here (tools/calib_gather.hip), the rate at which the L2s serve random 64-byte requests: 80.9 G/s.  Algorithmic bytes follow SURVEY §8(d); counter-based bytes and VALU instruction counts per work item
 come from the committed rocprofv3 --pmc passes of this same command (profiles/r02_pmc_<workload>.json, tools/profile_round.sh),
 labelled with their source — they are not measured by this run.
 """
@@ -40,6 +40,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 L2_PEAK_GBS = 34500.0       # aggregate over the 8 XCD L2s
 VALU_PEAK_TLOPS = 78.6432   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz, in 1e12 lane-ops/s
+L2_REQ_PEAK_G = 80.9        # random 64-byte read requests the L2s serve per second, all hits (measured: profiles/r02_calib_gather.md)
 HBM_TARGET_FRAC = 0.40      # north_star: ">= 40 % of HBM peak on the traversal kernel"
 
 WORKLOADS = {
@@ -153,6 +154,12 @@ def kernel_block(name, items, item_name, ms, launches, alg_bytes_per_item, pmc, 
             out["valu"] = {"wave_insts_per_%s" % item_name[:-1]: round(k["valu_insts_per_item"], 1), "achieved_Tlaneops": round(tl, 2),
                            "peak_Tlaneops": VALU_PEAK_TLOPS, "frac": round(tl / VALU_PEAK_TLOPS, 4), **src}
             ceilings["valu-issue"] = (tl, VALU_PEAK_TLOPS, "Tlane-op/s")
+        if k.get("l2_read_requests_per_item") is not None:
+            rq = items * k["l2_read_requests_per_item"] / sec / 1e9 if sec > 0 else 0.0
+            out["l2_requests"] = {"per_%s" % item_name[:-1]: round(k["l2_read_requests_per_item"], 2), "achieved_Greq_per_s": round(rq, 2),
+                                  "peak_Greq_per_s": L2_REQ_PEAK_G, "frac": round(rq / L2_REQ_PEAK_G, 4), "l2_hit_rate": k.get("l2_hit_rate"),
+                                  "l1_accesses_per_%s" % item_name[:-1]: k.get("l1_accesses_per_item"), **src}
+            ceilings["l2-request-rate"] = (rq, L2_REQ_PEAK_G, "Greq/s")
     # bytes the kernel requests from the cache hierarchy (= the algorithmic bytes) against the aggregate L2 bandwidth
     ceilings["l2"] = (alg, L2_PEAK_GBS, "GB/s")
     if "hbm" not in ceilings:

@@ -279,6 +279,11 @@ __global__ void __launch_bounds__(256) k_emit_sah(uint32_t n_in, const uint2* __
     count++;
   }
   Box3 boxes[4];
+  // the internal children of one node get CONSECUTIVE records (one reservation): siblings share 128-byte lines, and a ray that
+  // visits two children of a node finds the second one in the line the first one brought in
+  uint32_t n_internal = 0;
+  for (int k = 0; k < count; k++) n_internal += (refs[k] & kLeafBit) ? 0u : 1u;
+  uint32_t p = n_internal ? atomicAdd(n_out, n_internal) : 0u;
   for (int k = 0; k < count; k++) {
     Box3 e;
     for (int a = 0; a < 3; a++) { e.lo[a] = bx[k].lo[a]; e.hi[a] = bx[k].hi[a]; }
@@ -287,9 +292,9 @@ __global__ void __launch_bounds__(256) k_emit_sah(uint32_t n_in, const uint2* __
       const uint32_t pos = refs[k] & ~kLeafBit;
       refs[k] = leaf_tag | (remap ? order[pos] : pos);
     } else {
-      const uint32_t p = atomicAdd(n_out, 1u);
       q_out[p] = make_uint2(refs[k], next_base + p);
       refs[k] = ref_base + next_base + p;
+      p++;
     }
   }
   nodes[dense] = quantize_node4(boxes, refs, count);

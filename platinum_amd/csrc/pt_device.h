@@ -29,8 +29,10 @@ constexpr uint32_t kInstanceNonOpaque = 1u;
 static_assert(sizeof(InstanceInfo) == 64, "InstanceInfo");
 
 // ---- BVH -------------------------------------------------------------------------------------------------------
-// World-space triangle record in BVH leaf order, 48 B = 3 x dwordx4.
-struct alignas(16) TriRec {
+// World-space triangle record in BVH leaf order: 48 B of payload (3 x dwordx4) in a 64-byte-aligned slot, so that a
+// triangle test is ONE 64-byte L2 request (48-byte records straddle a sector boundary every other time; the C3 closest-hit
+// kernel runs at ~90 % of the L2's random-request rate, tools/calib_gather.hip, so requests are what count).
+struct alignas(64) TriRec {
   float v0[3];
   float e1[3];
   float e2[3];
@@ -38,7 +40,7 @@ struct alignas(16) TriRec {
   uint32_t prim;   // primitive id inside the instance's mesh
   uint32_t gid;    // global id = InstanceInfo.tri_global_base + prim : the closest-hit tie-break key
 };
-static_assert(sizeof(TriRec) == 48, "TriRec");
+static_assert(sizeof(TriRec) == 64, "TriRec");
 
 // What shading needs to know about a hit triangle, resolved once per render (k_shade_records) and indexed like tris[]:
 // absolute vertex indices, the absolute index of its MaterialGPU, its instance, and the world-space geometric normal

@@ -3,7 +3,8 @@
 import csv, glob, sys
 from collections import defaultdict
 def short(name):
-    for k in ("k_trace_closest<false>", "k_trace_shadow<false>", "k_shade", "k_raygen", "k_accumulate"):
+    for k in ("k_trace_closest<false, false>", "k_trace_shadow<false, false>", "k_trace_closest<false, true>", "k_trace_shadow<false, true>",
+              "k_shade", "k_raygen", "k_accumulate"):
         if k in name: return k
     return None
 acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))

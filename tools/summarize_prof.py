@@ -9,8 +9,8 @@
 Units and corrections as MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports
 half of the bytes of wide coalesced streaming reads.  The factor is CALIBRATED here on the two kernels whose byte counts
 are known exactly: k_accumulate reads (S+1) * 16 B and writes 16 B per pixel, k_raygen writes 68 B per path.
-The traversal kernels read 64-B nodes / 48-B triangle records as 16-B-per-lane gathers — a pattern the guide leaves
-uncalibrated — so their read traffic is given raw and corrected (x the calibrated streaming factor = an upper bound)."""
+The traversal kernels read 64-B nodes / triangle slots as 16-B-per-lane gathers — a pattern the guide leaves uncalibrated;
+tools/calib_gather.hip calibrated it (profiles/r02_calib_gather.md): FETCH_SIZE is exact for it, so those kernels get x1."""
 import csv, glob, hashlib, json, os, shutil, sys
 from collections import defaultdict
 
@@ -19,11 +19,18 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(root, "profiles")
 os.makedirs(out_dir, exist_ok=True)
 
-KEYS = ("k_trace_closest<false>", "k_trace_closest<true>", "k_trace_shadow<false>", "k_trace_shadow<true>", "k_shade_nee", "k_shade", "k_raygen",
-        "k_accumulate", "k_fold_counters", "k_chunk_tables", "k_refit", "k_karras", "k_emit", "k_morton", "k_flatten", "k_bounds", "k_hit_records")
+KEYS = ("k_shade", "k_raygen", "k_accumulate", "k_fold_counters", "k_chunk_tables", "k_refit", "k_karras", "k_emit", "k_morton", "k_flatten",
+        "k_bounds", "k_hit_records", "k_weighted_add", "k_postprocess", "k_gmon")
 
 
 def short(name):
+    """k_trace_closest<COUNT, TWO>: the render instantiation of the one-BVH kernel is the bare name; the instrumented and the
+    two-level instantiations are tagged."""
+    import re
+    m = re.search(r"(k_trace_closest|k_trace_shadow)<(?:\(bool\))?(\w+), (?:\(bool\))?(\w+)>", name)
+    if m:
+        count, two = m.group(2) in ("true", "1"), m.group(3) in ("true", "1")
+        return m.group(1) + ("[count]" if count else "") + ("[two-level]" if two else "")
     for k in KEYS:
         if k in name:
             return k
@@ -64,6 +71,7 @@ def counters(kind):
 fetch, jf = counters("fetch")
 write, jw = counters("write")
 sq, js = counters("sq")
+tc, jt = counters("tc")
 
 
 def items(j):
@@ -72,12 +80,12 @@ def items(j):
         return {}
     e, c = j["extra"], j["config"]
     npix, spp = c["width"] * c["height"], c["spp_per_gpu"]
-    return {"k_trace_closest<false>": e["closest_rays"], "k_trace_shadow<false>": e["shadow_rays"], "k_shade": e["shaded_hits"],
-            "k_shade_nee": e["shaded_hits"], "k_raygen": e["paths"], "k_accumulate": npix * spp, "_npix": npix, "_spp_per_step": c["spp_per_step"],
+    return {"k_trace_closest": e["closest_rays"], "k_trace_shadow": e["shadow_rays"], "k_trace_closest[two-level]": e["closest_rays"],
+            "k_trace_shadow[two-level]": e["shadow_rays"], "k_shade": e["shaded_hits"], "k_raygen": e["paths"], "k_accumulate": npix * spp, "_npix": npix, "_spp_per_step": c["spp_per_step"],
             "_steps": j["steps"]}
 
 
-itf, itw, its = items(jf), items(jw), items(js)
+itf, itw, its, itt = items(jf), items(jw), items(js), items(jt)
 
 # ---- calibration on known byte counts ----
 calib = {}
@@ -99,19 +107,21 @@ if "k_raygen" in write and itw:
     calib["k_raygen_write_bytes_expected"] = expect
     calib["k_raygen_WRITE_SIZE_bytes_raw"] = raw
 ff = calib.get("fetch_streaming_factor") or 2.0
+# Random 64-byte gathers (what the traversal kernels fetch) are reported exactly: profiles/r02_calib_gather.md
+GATHER_FACTOR = {"k_trace_closest": 1.0, "k_trace_shadow": 1.0, "k_trace_closest[two-level]": 1.0, "k_trace_shadow[two-level]": 1.0}
 
 lines = [f"# rocprofv3 summary — bench.py --workload {wl} (MI355X, {tag})", "",
          "Durations: `rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --no-cpu-baseline` (both of bench.py's passes)." % wl,
          "Counters: separate `--pmc` passes of `bench.py --workload %s --pmc-pass --steps 2` (full 64-spp batches only)." % wl, "",
          "Calibration on known byte counts: " + json.dumps({k: (round(v, 4) if isinstance(v, float) and v < 100 else v) for k, v in calib.items()}), "",
-         "| kernel | calls | total ms | avg ms | FETCH raw MiB/launch | FETCH x%.2f MiB/launch | WRITE MiB/launch | HBM B/item (corr.) | VALU wave-insts/item | items |" % ff,
+         "| kernel | calls | total ms | avg ms | FETCH raw MiB/launch | FETCH corrected MiB/launch (x%.2f streams, x1 gathers: r02_calib_gather.md) | WRITE MiB/launch | HBM B/item (corr.) | VALU wave-insts/item | items |" % ff,
          "|---|---|---|---|---|---|---|---|---|---|"]
 pmc = {"source": f"rocprofv3 --pmc passes of `bench.py --workload {wl} --pmc-pass --steps 2` ({tag}); tools/summarize_prof.py",
        "calibration": calib, "kernels": {}}
 lib = os.environ.get("PTAMD_LIB", os.path.join(root, "platinum_amd", "csrc", "libptamd.so"))
 if os.path.exists(lib):
     pmc["library_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
-names = sorted(set(summary) | set(fetch) | set(write) | set(sq), key=lambda k: -summary.get(k, {"total_ms": 0})["total_ms"])
+names = sorted(set(summary) | set(fetch) | set(write) | set(sq) | set(tc), key=lambda k: -summary.get(k, {"total_ms": 0})["total_ms"])
 for k in names:
     d = summary.get(k, {"calls": 0, "total_ms": 0.0})
     fn, fv = fetch[k]["FETCH_SIZE"] if k in fetch else (0, 0.0)
@@ -120,19 +130,26 @@ for k in names:
     fl = fv / fn / 1024.0 if fn else float("nan")
     wr = wv / wn / 1024.0 if wn else float("nan")
     ni_f, ni_w, ni_s = itf.get(k), itw.get(k), its.get(k)
-    per_item = (ff * fv * 1024.0 / ni_f + wv * 1024.0 / ni_w) if (ni_f and ni_w and fn and wn) else None
+    kf = GATHER_FACTOR.get(k, ff)
+    per_item = (kf * fv * 1024.0 / ni_f + wv * 1024.0 / ni_w) if (ni_f and ni_w and fn and wn) else None
     valu = vv / ni_s if (ni_s and vn) else None
     avg = d["total_ms"] / d["calls"] if d["calls"] else float("nan")
-    lines.append(f"| {k} | {d['calls']} | {d['total_ms']:.3f} | {avg:.4f} | {fl:.1f} | {ff*fl:.1f} | {wr:.1f} | "
+    lines.append(f"| {k} | {d['calls']} | {d['total_ms']:.3f} | {avg:.4f} | {fl:.1f} | {kf*fl:.1f} | {wr:.1f} | "
                  f"{'%.1f' % per_item if per_item is not None else '-'} | {'%.1f' % valu if valu is not None else '-'} | {ni_s or ni_f or '-'} |")
     if per_item is not None or valu is not None:
         e = {"hbm_bytes_per_item": per_item, "fetch_bytes_raw_per_item": fv * 1024.0 / ni_f if (ni_f and fn) else None,
-             "write_bytes_per_item": wv * 1024.0 / ni_w if (ni_w and wn) else None, "fetch_correction": ff, "valu_insts_per_item": valu}
+             "write_bytes_per_item": wv * 1024.0 / ni_w if (ni_w and wn) else None, "fetch_correction": kf, "valu_insts_per_item": valu}
         if k in sq:
             for c in ("SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY"):
                 if c in sq[k] and ni_s:
                     e[c.lower() + "_per_item"] = sq[k][c][1] / ni_s
-        pmc["kernels"][k.replace("<false>", "")] = e
+        if k in tc and itt.get(k):
+            t = tc[k]
+            e["l2_read_requests_per_item"] = t["TCP_TCC_READ_REQ_sum"][1] / itt[k] if "TCP_TCC_READ_REQ_sum" in t else None
+            e["l1_accesses_per_item"] = t["TCP_TOTAL_CACHE_ACCESSES_sum"][1] / itt[k] if "TCP_TOTAL_CACHE_ACCESSES_sum" in t else None
+            if "TCC_HIT_sum" in t and "TCC_MISS_sum" in t and (t["TCC_HIT_sum"][1] + t["TCC_MISS_sum"][1]) > 0:
+                e["l2_hit_rate"] = t["TCC_HIT_sum"][1] / (t["TCC_HIT_sum"][1] + t["TCC_MISS_sum"][1])
+        pmc["kernels"][k] = e
 open(os.path.join(out_dir, f"{tag}_{wl}_summary.md"), "w").write("\n".join(lines) + "\n")
 if pmc["kernels"]:
     json.dump(pmc, open(os.path.join(out_dir, f"r02_pmc_{wl}.json"), "w"), indent=1)
