@@ -77,6 +77,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline sample")
     ap.add_argument("--inproc", action="store_true", help="N > 1: one process, the library's own multi-device path")
     ap.add_argument("--devices", default="", help="--inproc: explicit HIP ordinals, e.g. 0,0 = two logical shards on one GPU (rehearsal)")
+    ap.add_argument("--rehearse-on-device0", action="store_true",
+                    help="N > 1 on a ONE-GPU box: every rank renders on device 0 and the all-reduce goes through gloo (RCCL refuses two ranks "
+                         "on one device) — exercises the launcher, sharding and timing code, not xGMI")
     ap.add_argument("--pmc-pass", action="store_true",
                     help="under rocprofv3 --pmc: only full-size batches (no warm-up, no instrumented sample, no CPU leg, no event timing)")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the second (event-timed) pass")
@@ -196,11 +199,16 @@ def main():
     if not inproc and world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
+    if args.rehearse_on_device0:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        if args.rehearse_on_device0:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
 
     from platinum_amd import Renderer, abi, scenes
     from platinum_amd.sharding import reduce_accumulator, shard_samples
@@ -332,7 +340,8 @@ def main():
             "integrator": "MIS+NEE", "flags": "MultiscatterGGX", "triangles": int(st.triangles),
             "nonfinite_policy": "zero (a NaN/inf sample counts as black; parity default is propagate)",
             "parallelism": ("sample-sharded x%d, one process, library multi-device + RCCL" % n_gpus) if inproc else
-                           ("sample-sharded x%d, one process per GPU + RCCL all-reduce" % n_gpus),
+                           ("sample-sharded x%d, one process per GPU + RCCL all-reduce" % n_gpus) +
+                           (" [REHEARSAL: all ranks on device 0, gloo]" if args.rehearse_on_device0 else ""),
         },
         "roofline": roofline,
         "roofline_kernels": blocks,
