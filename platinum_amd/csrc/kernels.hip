@@ -289,7 +289,7 @@ k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments se
   uint32_t ray = kInvalidRef;
   auto finish = [&]() {
     const RayHit& h = ts.best;
-    hit[ray] = vec4{h.t, h.u, h.v, u2f(h.tri)};
+    hit[ray] = vec4{h.t, h.u, h.v, u2f(h.tri == kInvalidRef ? kInvalidRef : (h.tri | ((h.gid & 3u) << 28)))};
     if (hitlog) {
       const uint32_t pid = st.pid[ray];
       int32_t* hl = &hitlog[((size_t)bounce * log_stride + pid) * 2];
@@ -351,6 +351,7 @@ constexpr uint32_t kShadeBlock = PT_SHADE_BLOCK;
 constexpr uint32_t kShadeHalton = 128;  // staged Halton window (entries); dimensions beyond it are read from HBM
 constexpr uint32_t kShadeLights = 64;   // staged area lights; a bigger table is read from HBM
 constexpr int kLutE = 128, kLutEavg = 128, kLutEavgMs = 32;  // table shapes (checked by load_luts)
+constexpr uint32_t kBinCap = 128;       // a bin is emptied as soon as it holds 64 entries, and a scan step adds at most 64
 
 __global__ void __launch_bounds__(PT_SHADE_BLOCK, (PT_SHADE_WAVES * 4 * 64) / PT_SHADE_BLOCK)
 k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const vec4* __restrict__ hit, ShadowQueue sq,
@@ -360,6 +361,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
   __shared__ pt_area_light lds_lights[kShadeLights];
   __shared__ float lds_Eavg[kLutEavg];
   __shared__ float lds_EavgMs[kLutEavgMs * kLutEavgMs];
+  __shared__ uint16_t lds_bins[kShadeBlock / 64][5][kBinCap];  // per wave: slot numbers by material class (+ misses), 1.25 KB
 #if PT_SHADE_LDS_E
   __shared__ float lds_E[kLutE * kLutE];
 #endif
@@ -408,18 +410,62 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
   // first segment = the wave's index; further ones are claimed from a per-launch cursor (segments differ in size by the
   // time the later bounces are reached, so a static deal would leave waves idle at the end of every launch)
   uint32_t sg = wave_index();
+  uint16_t* bin = &lds_bins[threadIdx.x >> 6][0][0];  // this wave's bins: [class][kBinCap] slot numbers within the segment
   while (sg < seg.nseg) {
     const uint32_t n = seg.active[cur][sg];
     uint32_t n_out = 0, n_shadow = 0;
-    for (uint32_t k0 = 0; k0 < n; k0 += 64) {  // wave-uniform trip count
-      const uint32_t k = k0 + lane;
-      const uint32_t i = seg_slot(seg.nseg, sg, k);
-      uint32_t tri = kInvalidRef;
-      vec4 h4{};
-      if (k < n) { h4 = hit[i]; tri = f2u(h4.w); }
-      if (k < n && tri == kInvalidRef && S.env_texture >= 0) {
-        // a miss ends the path; it adds the environment's radiance if there is one (kernel.metal:517-539), then
-        // attenuation * backgroundColor (= 0, defs.metal:21)
+    // ---- hits are shaded one MATERIAL CLASS per wave pass.  The segment is scanned 64 slots at a time; every slot number goes
+    //      to the LDS bin of its hit's class (4 lobe classes + misses); as soon as a bin holds 64 entries they are shaded
+    //      together; what is left at the end of the segment is shaded in mixed passes.  (Measured on C3: the same kernel costs
+    //      0.092 ns per hit when every sphere is diffuse and 0.126 with the per-instance material mix.)
+    uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt4 = 0;  // wave-uniform bin fill levels
+    uint32_t k0 = 0;
+    for (;;) {
+      while (k0 < n && cnt0 < 64 && cnt1 < 64 && cnt2 < 64 && cnt3 < 64 && cnt4 < 64) {
+        const uint32_t k = k0 + lane;
+        uint32_t cls = 5;  // no entry
+        if (k < n) {
+          const uint32_t w = f2u(hit[seg_slot(seg.nseg, sg, k)].w);
+          cls = w == kInvalidRef ? 4u : (w >> 28) & 3u;
+          if (cls == 4u && S.env_texture < 0) cls = 5u;  // a miss without an environment adds nothing (defs.metal:21)
+        }
+        const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3),
+                                 m4 = __ballot(cls == 4);
+        if (cls < 5) {
+          const uint32_t at = cls == 0 ? cnt0 + wave_prefix(m0) : cls == 1 ? cnt1 + wave_prefix(m1) : cls == 2 ? cnt2 + wave_prefix(m2)
+                            : cls == 3 ? cnt3 + wave_prefix(m3) : cnt4 + wave_prefix(m4);
+          bin[cls * kBinCap + at] = (uint16_t)k;
+        }
+        cnt0 += (uint32_t)__popcll(m0); cnt1 += (uint32_t)__popcll(m1); cnt2 += (uint32_t)__popcll(m2);
+        cnt3 += (uint32_t)__popcll(m3); cnt4 += (uint32_t)__popcll(m4);
+        k0 += 64;
+      }
+      // one pass: a full bin if there is one, else (segment scanned) whatever is left, class by class
+      uint32_t k = kInvalidRef;
+      bool is_miss = false;
+      const uint32_t full = cnt0 >= 64 ? 0u : cnt1 >= 64 ? 1u : cnt2 >= 64 ? 2u : cnt3 >= 64 ? 3u : cnt4 >= 64 ? 4u : 5u;
+      if (full < 5) {
+        uint32_t& c = full == 0 ? cnt0 : full == 1 ? cnt1 : full == 2 ? cnt2 : full == 3 ? cnt3 : cnt4;
+        c -= 64;
+        k = bin[full * kBinCap + c + lane];
+        is_miss = full == 4;
+      } else {
+        if (cnt0 + cnt1 + cnt2 + cnt3 + cnt4 == 0) break;
+        // (k0 >= n here) fill the pass from the bins in class order
+        uint32_t taken = 0;
+        uint32_t* cs[5] = {&cnt0, &cnt1, &cnt2, &cnt3, &cnt4};
+#pragma unroll
+        for (uint32_t c = 0; c < 5; c++) {
+          const uint32_t take = *cs[c] < 64 - taken ? *cs[c] : 64 - taken;
+          if (lane >= taken && lane < taken + take) { k = bin[c * kBinCap + *cs[c] - take + (lane - taken)]; is_miss = c == 4; }
+          *cs[c] -= take;
+          taken += take;
+        }
+      }
+      const bool has = k != kInvalidRef && !is_miss;
+      const uint32_t i = seg_slot(seg.nseg, sg, k != kInvalidRef ? k : 0u);
+      if (k != kInvalidRef && is_miss) {
+        // a miss ends the path; it adds the environment's radiance (kernel.metal:517-539)
         const vec4 o4 = sin.rayO[i];
         const vec4 d4 = sin.rayD[i];
         const vec4 a4 = sin.att[i];
@@ -429,9 +475,9 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
         L.x += Le.x; L.y += Le.y; L.z += Le.z;
         Lbuf[mpid] = L;
       }
-      const bool has = tri != kInvalidRef;
       uint32_t c_shadow = 0, c_alive = 0;  // written by the lanes inside the divergent region, made wave-uniform after it
       if (has) {
+        const vec4 h4 = hit[i];
         const vec4 o4 = sin.rayO[i];
         const vec4 d4 = sin.rayD[i];
         const vec4 a4 = sin.att[i];
@@ -448,7 +494,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
         in.dim = (meta & kMetaDimMask) + 1;  // +1: the alpha-test payload `ir` drawn before intersect (kernel.metal:510)
         in.bounce = bounce;
         in.t = h4.x; in.u = h4.y; in.v = h4.z;
-        in.tri = tri;
+        in.tri = f2u(h4.w) & kHitTriMask;
         ShadeGeom g;
         ShadingContext sc;
         shade_geometry(S, in, g, sc);
@@ -730,7 +776,7 @@ __global__ void __launch_bounds__(kBlock) k_hit_records(DeviceScene S, PathState
     for (uint32_t k = lane; k < n; k += 64) {
       const uint32_t i = seg_slot(seg.nseg, sg, k);
       const vec4 h = hit[i];
-      const uint32_t tri = f2u(h.w);
+      const uint32_t tri = f2u(h.w) == kInvalidRef ? kInvalidRef : (f2u(h.w) & kHitTriMask);
       pt_hit_record r;
       if (tri != kInvalidRef) {
         r.t = h.x; r.u = h.y; r.v = h.z;

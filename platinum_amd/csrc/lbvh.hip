@@ -51,7 +51,8 @@ __global__ void __launch_bounds__(256) k_flatten(DeviceScene S, uint32_t instanc
   t.v0[0] = v0.x; t.v0[1] = v0.y; t.v0[2] = v0.z;
   t.e1[0] = e1.x; t.e1[1] = e1.y; t.e1[2] = e1.z;
   t.e2[0] = e2.x; t.e2[1] = e2.y; t.e2[2] = e2.z;
-  t.inst = lo; t.prim = prim; t.gid = g;
+  t.inst = lo; t.prim = prim;
+  t.gid = (g << 2) | material_class(S.materials[inst.material_base + S.slots[mesh.tri_base + prim]]);
   tris[g] = t;
   Box b;
   b.lo[0] = fminf(v0.x, fminf(v1.x, v2.x)); b.hi[0] = fmaxf(v0.x, fmaxf(v1.x, v2.x));

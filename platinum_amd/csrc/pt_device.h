@@ -38,9 +38,14 @@ struct alignas(64) TriRec {
   float e2[3];
   uint32_t inst;   // instance id
   uint32_t prim;   // primitive id inside the instance's mesh
-  uint32_t gid;    // global id = InstanceInfo.tri_global_base + prim : the closest-hit tie-break key
+  uint32_t gid;    // (global id << 2) | material class; global id = InstanceInfo.tri_global_base + prim is the closest-hit
+                   // tie-break key (the class bits sit below it, so comparing this field orders by global id)
 };
 static_assert(sizeof(TriRec) == 64, "TriRec");
+// Hit record word 3: triangle index (28 bits) | material class << 28; kInvalidRef = miss.  The class (which BSDF lobes the
+// material can take: see material_class) lets k_shade put hits of one kind into one wave.
+constexpr uint32_t kHitTriMask = 0x0fffffffu;
+constexpr uint32_t kShadeClasses = 4;
 
 // What shading needs to know about a hit triangle, resolved once per render (k_shade_records) and indexed like tris[]:
 // absolute vertex indices, the absolute index of its MaterialGPU, its instance, and the world-space geometric normal

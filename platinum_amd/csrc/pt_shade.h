@@ -42,6 +42,15 @@ PT_HD vec3 ld3(const pt_float3& v) { return v3(v.x, v.y, v.z); }
 // defs.metal:27-30
 PT_HD vec3 interpolate3(vec3 a0, vec3 a1, vec3 a2, float u, float v) { return ((1.0f - u - v) * a0 + u * a1) + v * a2; }
 
+// Which lobes of BSDF::sample / eval (bsdf.metal:199-252) a material can take — the divergence class of a hit:
+//   0 opaque dielectric only, 1 + metallic, 2 + transmission, 3 clearcoat or anything textured that may switch lobes per texel.
+PT_HD uint32_t material_class(const pt_material_gpu& m) {
+  if (m.clearcoat > 0.0f || m.clearcoatTextureId >= 0 || m.rmTextureId >= 0 || m.transmissionTextureId >= 0) return 3u;
+  if (m.transmission > 0.0f) return 2u;
+  if (m.metallic > 0.0f) return 1u;
+  return 0u;
+}
+
 // getIntersectionData's table walk (kernel.metal:118-141) and its geometric normal (:150-162), done once per flattened
 // triangle instead of once per hit
 PT_HD ShadeRec make_shade_rec(const DeviceScene& S, const TriRec& tr) {

@@ -252,6 +252,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
     const int rc = build_host_scene(scene, p, r->lut_w_E, r->lut_w_Eavg, &hs, &err);
     if (rc != PT_OK) return fail(rc, err);
   }
+  if (hs.tri_count >= (1u << 28)) return fail(PT_ERR_UNSUPPORTED, "more than 2^28 flattened triangles (the hit record keeps 28 bits for the triangle)");
   r->instance_count = (uint32_t)hs.instances.size();
   r->tri_count = hs.tri_count;
   r->constants = hs.constants;
