@@ -16,7 +16,7 @@
 // grid can be sized for whatever occupancy a kernel's registers allow and the tile count never has to divide it.
 // The trace kernels consume DENSE CHUNK TABLES: after every producer, k_chunk_tables lists the non-empty 64-entry
 // chunks of all segments, segment-major (= image tiles in raster order, each under its samples), and the trace waves
-// claim runs of that list from one cursor (kClaim chunks per atomic): the rays in flight at any moment come from a
+// claim runs of that list from one cursor (8 chunks per atomic, fewer towards the end of the list): the rays in flight at any moment come from a
 // small neighbourhood of the image — the BVH subtrees they touch stay in L2 — there are no empty chunks to sweep, and
 // a chunk of survivors still comes from one tile.  Results are written in place (hit[i], Lbuf[pid]), so it does not
 // matter which wave traces a ray.  Statistics are kept per physical wave (no atomics) and reduced by k_fold_counters.
@@ -48,7 +48,12 @@ __device__ __forceinline__ uint32_t wave_count() { return gridDim.x * (blockDim.
 __device__ __forceinline__ uint32_t seg_slot(uint32_t nseg, uint32_t s, uint32_t r) { return ((r >> 6) * nseg + s) * 64u + (r & 63u); }
 
 // ---- chunk claims for the trace kernels ------------------------------------------------------------------------------
-constexpr uint32_t kClaim = 2;  // 64-ray chunks claimed per cursor atomic
+// 64-ray chunks claimed per cursor atomic.  ONE L2 address sustains ~88 returning atomics per microsecond
+// (MI355X_MICROARCH.md "dequeue"); at 2 chunks per claim the C2 closest-hit kernel (10.6 Grays/s = 166 chunks/us) ran AT that
+// limit and C3 at two thirds of it — 73 % of the C2 kernel's wave time was s_waitcnt.  Claims are therefore "guided": 8 chunks
+// while plenty of work is left, then 4, 2, 1 towards the end of the list so that the last waves finish together
+// (a fixed 8 costs C3 3 % in the tail; guided, C2 closest-hit went from 36.2 to 23.0 ms per step, shadow from 26.0 to 15.4).
+constexpr uint32_t kClaimMax = 8;
 
 struct ChunkClaims {
   const uint32_t* __restrict__ table;   // [total] (k << 16) | s  for every non-empty chunk, segment-major
@@ -56,10 +61,16 @@ struct ChunkClaims {
   uint32_t* cursor;
   uint32_t nseg, total, lane;
   uint32_t next_c, end_c;
+  uint32_t claim_k = kClaimMax, nwaves_grid = 1;
   __device__ __forceinline__ void init(const uint32_t* tab, uint32_t total_, const uint32_t* c, uint32_t* cur, const Segments& seg,
                                        uint32_t lane_) {
     table = tab; total = total_; counts = c; cursor = cur; nseg = seg.nseg; lane = lane_;
     next_c = end_c = 0;
+    nwaves_grid = gridDim.x * (blockDim.x >> 6);
+    claim_k = guided(total);
+  }
+  __device__ __forceinline__ uint32_t guided(uint32_t remaining) const {
+    return remaining > 32u * nwaves_grid ? kClaimMax : remaining > 8u * nwaves_grid ? 4u : remaining > 2u * nwaves_grid ? 2u : 1u;
   }
   // ---- per-lane ray replacement ----
   // The wave keeps a pool = the not yet started rays [pool_next, pool_end) of its current chunk.  Lanes whose ray has
@@ -76,11 +87,12 @@ struct ChunkClaims {
         if (exhausted) return got;
         if (next_c == end_c) {
           uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(cursor, kClaim);
+          if (lane == 0) base = atomicAdd(cursor, claim_k);
           base = __builtin_amdgcn_readfirstlane(base);
           if (base >= total) { exhausted = true; return got; }
           next_c = base;
-          end_c = base + kClaim < total ? base + kClaim : total;
+          end_c = base + claim_k < total ? base + claim_k : total;
+          claim_k = guided(total - end_c);
         }
         const uint32_t e = table[next_c++];
         const uint32_t sg = e & 0xffffu, k = e >> 16;
