@@ -204,7 +204,8 @@ def test_present_render_target_is_the_readback_image_on_the_device(gpu_renderer)
     assert ptr and stream
     want = gpu_renderer.readbackRenderTarget()      # (synchronises the renderer's stream)
     import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
+    from platinum_amd import abi
+    hip = abi.load_library()   # dlsym on the library's handle also searches its dependencies: the HIP runtime it renders with
     got = np.empty((h, w, 4), np.uint8)
     assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), C.c_void_p(ptr), C.c_size_t(got.nbytes), 2) == 0  # hipMemcpyDeviceToHost
     assert np.array_equal(got, want) and want[..., 3].min() == 255
