@@ -370,7 +370,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
         vec4* __restrict__ Lbuf, Segments seg, uint32_t cur, BatchCounters* __restrict__ ctr, uint32_t bounce) {
   const DeviceScene& S = *Sp;  // scene table read through the scalar cache: by value it cost 100 spilled SGPRs here
   __shared__ HaltonEntry lds_halton[kShadeHalton];
-  __shared__ pt_area_light lds_lights[kShadeLights];
+  __shared__ LightRec lds_lights[kShadeLights];
   __shared__ float lds_Eavg[kLutEavg];
   __shared__ float lds_EavgMs[kLutEavgMs * kLutEavgMs];
   __shared__ uint16_t lds_bins[kShadeBlock / 64][5][kBinCap];  // per wave: slot numbers by material class (+ misses), 1.25 KB
@@ -388,9 +388,9 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
     uint4* dst = reinterpret_cast<uint4*>(lds_halton);
     for (uint32_t i = threadIdx.x; i < halton_count * 2; i += kShadeBlock) dst[i] = ldg(&src[i]);
     if (lights_in_lds) {
-      const uint4* ls = reinterpret_cast<const uint4*>(S.lights);
+      const uint4* ls = reinterpret_cast<const uint4*>(S.light_recs);
       uint4* ld = reinterpret_cast<uint4*>(lds_lights);
-      for (uint32_t i = threadIdx.x; i < S.lightCount * 3; i += kShadeBlock) ld[i] = ldg(&ls[i]);
+      for (uint32_t i = threadIdx.x; i < S.lightCount * (uint32_t)(sizeof(LightRec) / 16); i += kShadeBlock) ld[i] = ldg(&ls[i]);
     }
     for (uint32_t i = threadIdx.x; i < (uint32_t)kLutEavg; i += kShadeBlock) lds_Eavg[i] = ldg(&S.luts.Eavg.d[i]);
     for (uint32_t i = threadIdx.x; i < (uint32_t)(kLutEavgMs * kLutEavgMs); i += kShadeBlock) lds_EavgMs[i] = ldg(&S.luts.EavgMs.d[i]);
@@ -414,7 +414,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
   T.luts.E = Lut{lds_E, kLutE, kLutE, 1, 1};
 #endif
   T.halton = HaltonTab{S.halton, lds_halton, halton_base, halton_count};
-  T.lights = lights_in_lds ? lds_lights : S.lights;
+  T.lights = lights_in_lds ? lds_lights : S.light_recs;
   T.lights_lds = lights_in_lds ? 1 : 0;
 
   const uint32_t lane = wave_lane();
@@ -772,6 +772,12 @@ __global__ void __launch_bounds__(kBlock) k_fold_counters(const BatchCounters* _
   }
 }
 
+// one LightRec per area light (once per render)
+__global__ void __launch_bounds__(kBlock) k_light_records(DeviceScene S, LightRec* __restrict__ out) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < S.lightCount) out[i] = make_light_rec(S, S.lights[i]);
+}
+
 // one ShadeRec per flattened triangle, in tris[] order (once per render, after the BVH build)
 __global__ void __launch_bounds__(kBlock) k_shade_records(DeviceScene S, ShadeRec* __restrict__ out) {
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
@@ -869,6 +875,9 @@ void launch_fold_counters(hipStream_t s, const BatchCounters* ctr, Totals* tot, 
 }
 void launch_shade_records(hipStream_t s, const DeviceScene& S, ShadeRec* out) {
   if (S.tri_count) hipLaunchKernelGGL(k_shade_records, dim3((S.tri_count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, S, out);
+}
+void launch_light_records(hipStream_t s, const DeviceScene& S, LightRec* out) {
+  if (S.lightCount) hipLaunchKernelGGL(k_light_records, dim3((S.lightCount + kBlock - 1) / kBlock), dim3(kBlock), 0, s, S, out);
 }
 void launch_hit_records(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, const vec4* hit, Segments seg,
                         pt_hit_record* out) {

@@ -113,6 +113,22 @@ static_assert(sizeof(InstanceTrav) == 64, "InstanceTrav");
 struct alignas(16) MeshTrav { uint32_t root_ref, _pad; float lo[3], hi[3]; };  // 32 B: BLAS root, object-space bounds
 static_assert(sizeof(MeshTrav) == 32, "MeshTrav");
 
+// ---- one record per area light: what sampleLightPower / sampleAreaLight (kernel.metal:379-435) read ---------------
+// The reference walks light -> instance -> mesh -> three vertices for every light sample; the walk and the light's
+// world-space normal do not depend on the sample, so they are resolved once per render (make_light_rec, the same
+// arithmetic in the same order) and the stage reads ONE record — from LDS when the table has at most 64 entries.
+struct alignas(16) LightRec {   // 128 B
+  float q0[3], area;            // object-space vertices (AreaLight::indices resolved), AreaLight::area
+  float q1[3], power;
+  float q2[3], cumulativePower;
+  float c0[3], e0;              // the instance's object->world columns; e = AreaLight::emission
+  float c1[3], e1;
+  float c2[3], e2;
+  float c3[3], _pad0;
+  float n[3], _pad1;            // normalize(transformVec(cross(q1 - q0, q2 - q0)))
+};
+static_assert(sizeof(LightRec) == 128, "LightRec");
+
 // ---- sampler table: one entry per Halton dimension (defs.metal:115-194 holds the 620 primes) ---------------------
 // 32-bit integer multiplies are quarter rate on CDNA, so the radical inverse peels `digits` base-`prime` digits per
 // division by chunk = prime^digits (the largest power below 2^22: two divisions cover a 32-bit index for every prime up to
@@ -155,6 +171,7 @@ struct DeviceScene {
   const BvhNode* nodes;
   const TriRec* tris;
   const ShadeRec* shade_recs;  // tri_count records, same order as tris[]
+  const LightRec* light_recs;  // lightCount records, same order as lights[]
   uint32_t tri_count;
   uint32_t root_ref;       // kLeafBit|0 for a single-triangle scene, the root's node index otherwise, kInvalidRef when empty
   const InstanceTrav* inst_trav;  // two-level structure only (two_level != 0): root_ref is the TLAS root, tris[] is in flattening order

@@ -68,6 +68,25 @@ PT_HD ShadeRec make_shade_rec(const DeviceScene& S, const TriRec& tr) {
   return r;
 }
 
+PT_HD LightRec make_light_rec(const DeviceScene& S, const pt_area_light& light) {
+  const InstanceInfo& linst = S.instances[light.instanceIdx];
+  const uint32_t vb = S.meshes[linst.mesh].vertex_base;
+  const vec3 q0 = ld3(S.positions[vb + light.indices[0]]);
+  const vec3 q1 = ld3(S.positions[vb + light.indices[1]]);
+  const vec3 q2 = ld3(S.positions[vb + light.indices[2]]);
+  const vec3 osNormal = cross(q1 - q0, q2 - q0);
+  const vec3 n = normalize(transformVec(osNormal, load_xform(linst)));  // kernel.metal:420-423
+  LightRec r;
+  r.q0[0] = q0.x; r.q0[1] = q0.y; r.q0[2] = q0.z; r.area = light.area;
+  r.q1[0] = q1.x; r.q1[1] = q1.y; r.q1[2] = q1.z; r.power = light.power;
+  r.q2[0] = q2.x; r.q2[1] = q2.y; r.q2[2] = q2.z; r.cumulativePower = light.cumulativePower;
+  for (int k = 0; k < 3; k++) { r.c0[k] = linst.c0[k]; r.c1[k] = linst.c1[k]; r.c2[k] = linst.c2[k]; r.c3[k] = linst.c3[k]; }
+  r.e0 = light.emission.x; r.e1 = light.emission.y; r.e2 = light.emission.z;
+  r.n[0] = n.x; r.n[1] = n.y; r.n[2] = n.z;
+  r._pad0 = 0.0f; r._pad1 = 0.0f;
+  return r;
+}
+
 // ---- raygen -----------------------------------------------------------------------------------------------------
 struct RayGenOut { vec3 o, d; uint32_t offset, dim; };
 
@@ -136,11 +155,11 @@ struct ShadeOut {
 struct ShadeTables {
   LutSet luts;
   HaltonTab halton;
-  const pt_area_light* lights;
+  const LightRec* lights;
   int lights_lds;
 };
-PT_HD ShadeTables shade_tables(const DeviceScene& S) { return {S.luts, halton_table(S.halton), S.lights, 0}; }
-PT_HD pt_area_light load_light(const ShadeTables& T, uint32_t i) { return T.lights_lds ? T.lights[i] : ldg(&T.lights[i]); }
+PT_HD ShadeTables shade_tables(const DeviceScene& S) { return {S.luts, halton_table(S.halton), S.light_recs, 0}; }
+PT_HD LightRec load_light(const ShadeTables& T, uint32_t i) { return T.lights_lds ? T.lights[i] : ldg(&T.lights[i]); }
 PT_HD float light_cumulative_power(const ShadeTables& T, uint32_t i) {
   return T.lights_lds ? T.lights[i].cumulativePower : ldg(&T.lights[i].cumulativePower);
 }
@@ -279,22 +298,19 @@ PT_HD NeeOut shade_nee(const DeviceScene& S, const ShadeTables& T, const ShadeIn
     Li = es.Li; lpos = es.wi * 100.0f; lwi = es.wi; lpdf = es.pdf;
   } else {
     rz = (rz - pInfinite) / (1.0f - pInfinite);
-    const pt_area_light light = load_light(T, sampleLightPower(S, T, rz));
+    const LightRec light = load_light(T, sampleLightPower(S, T, rz));
     pLight = (1.0f - pInfinite) * light.power / S.totalLightPower;
-    // sampleAreaLight (kernel.metal:407-435)
-    const InstanceInfo linst = ldg(&S.instances[light.instanceIdx]);
-    const uint32_t vb = ldg(&S.meshes[linst.mesh].vertex_base);
-    const vec3 q0 = ld3(ldg(&S.positions[vb + light.indices[0]]));
-    const vec3 q1 = ld3(ldg(&S.positions[vb + light.indices[1]]));
-    const vec3 q2 = ld3(ldg(&S.positions[vb + light.indices[2]]));
+    // sampleAreaLight (kernel.metal:407-435); vertices, transform and world-space normal come resolved in the record
+    const vec3 q0 = v3(light.q0[0], light.q0[1], light.q0[2]), q1 = v3(light.q1[0], light.q1[1], light.q1[2]),
+               q2 = v3(light.q2[0], light.q2[1], light.q2[2]);
     const vec2 sc = sampleTriUniform(rl);
-    const Xform lx = load_xform(linst);
-    const vec3 osNormal = cross(q1 - q0, q2 - q0);
+    const Xform lx = {v3(light.c0[0], light.c0[1], light.c0[2]), v3(light.c1[0], light.c1[1], light.c1[2]),
+                      v3(light.c2[0], light.c2[1], light.c2[2]), v3(light.c3[0], light.c3[1], light.c3[2])};
     lpos = transformPoint(interpolate3(q0, q1, q2, sc.x, sc.y), lx);
-    const vec3 lnormal = normalize(transformVec(osNormal, lx));
+    const vec3 lnormal = v3(light.n[0], light.n[1], light.n[2]);
     lwi = normalize(lpos - g.hitPos);
     lpdf = length_squared(lpos - g.hitPos) / (fabsf(dot(lnormal, lwi)) * light.area);
-    Li = ld3(light.emission);
+    Li = v3(light.e0, light.e1, light.e2);
   }
 
   const vec3 wi = g.frame.worldToLocal(lwi);

@@ -25,6 +25,7 @@ struct Emu {
   std::vector<HaltonEntry> halton;
   std::vector<TriRec> tris;
   std::vector<ShadeRec> shade_recs;
+  std::vector<LightRec> light_recs;
   std::vector<BvhNode> nodes;
   DeviceScene S{};
   pt_render_params params{};
@@ -297,6 +298,9 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
   e->shade_recs.resize(e->tris.size());
   for (size_t i = 0; i < e->tris.size(); i++) e->shade_recs[i] = make_shade_rec(S, e->tris[i]);
   S.shade_recs = e->shade_recs.data();
+  e->light_recs.resize(e->hs.lights.size());
+  for (size_t i = 0; i < e->hs.lights.size(); i++) e->light_recs[i] = make_light_rec(S, e->hs.lights[i]);
+  S.light_recs = e->light_recs.data();
   Lut* ls[6] = {&S.luts.E, &S.luts.Eavg, &S.luts.EMs, &S.luts.EavgMs, &S.luts.ETransIn, &S.luts.ETransOut};
   for (int i = 0; i < 6; i++) { ls[i]->w = hdr[4 * i]; ls[i]->h = hdr[4 * i + 1]; ls[i]->depth = hdr[4 * i + 2]; ls[i]->d = e->lut.data() + hdr[4 * i + 3]; }
   S.camera = e->hs.constants.camera; S.idt = e->hs.idt; S.width = p->width; S.height = p->height;
