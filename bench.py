@@ -314,7 +314,11 @@ def main():
             b = blocks.get(name)
             if b and "counter_frac_of_hbm_peak" in b["hbm"]:
                 b["hbm"]["target_frac"] = HBM_TARGET_FRAC
-                b["hbm"]["target_met"] = bool(b["hbm"]["counter_frac_of_hbm_peak"] >= HBM_TARGET_FRAC)
+                # two readings of the target: the contract's `achieved` (algorithmic bytes / launch time) and the
+                # stricter one on the bytes the HBM counters saw — caches serve most of the algorithmic bytes
+                b["hbm"]["target_met_algorithmic_bytes"] = bool(b["hbm"]["algorithmic_frac_of_hbm_peak"] >= HBM_TARGET_FRAC)
+                b["hbm"]["target_met_counter_bytes"] = bool(b["hbm"]["counter_frac_of_hbm_peak"] >= HBM_TARGET_FRAC)
+                b["hbm"]["target_met"] = b["hbm"]["target_met_counter_bytes"]
     times = {"k_trace_closest": ks.ms_closest, "k_shade": ks.ms_shade, "k_trace_shadow": ks.ms_shadow}
     dominant = max(times, key=times.get) if blocks else None
     roofline = dict(blocks[dominant]) if dominant else None

@@ -131,8 +131,9 @@ static_assert(sizeof(LightRec) == 128, "LightRec");
 
 // ---- sampler table: one entry per Halton dimension (defs.metal:115-194 holds the 620 primes) ---------------------
 // 32-bit integer multiplies are quarter rate on CDNA, so the radical inverse peels `digits` base-`prime` digits per
-// division by chunk = prime^digits (the largest power below 2^22: two divisions cover a 32-bit index for every prime up to
-// 2047, three beyond) and splits the remainder with exact fp32 arithmetic.  The division is the round-up multiply-shift of
+// division by chunk = prime^digits (the largest power below 2^22) and splits the remainder with exact fp32 arithmetic; a
+// quotient below `chunk` is the last remainder as it stands (one division covers a 32-bit index for every prime except
+// 163..251 and those from 2048 on, which need two).  The division is the round-up multiply-shift of
 // Granlund & Montgomery with a 33-bit multiplier 2^32 + magic, l = ceil(log2 chunk):
 //   t = mulhi(magic, n);  q = (t + ((n - t) >> 1)) >> (l - 1)          exact for every 32-bit n
 // — ONE quarter-rate multiply per chunk (q * chunk is a 24-bit multiply: q < 2^24 because chunk >= 257, chunk < 2^22).
@@ -144,7 +145,7 @@ struct alignas(16) HaltonEntry {
   float primef;      // (float)prime
   uint32_t digits;   // digits peeled per chunk (1 for primes >= 257)
   uint32_t prime;
-  uint32_t _pad;
+  float hinv;        // 0.5f * inv (exact)
 };
 constexpr int kHaltonDims = 620;
 

@@ -43,7 +43,8 @@ inline HaltonEntry make_halton_entry(uint32_t prime) {
   uint32_t l = 0;
   while ((1ull << l) < chunk) l++;  // l = ceil(log2 chunk)
   const uint64_t magic = ((1ull << 32) * ((1ull << l) - chunk)) / chunk + 1;  // < 2^32
-  return {(uint32_t)chunk, (uint32_t)magic, l - 1, 1.0f / (float)prime, (float)prime, digits, prime, 0u};
+  const float inv = 1.0f / (float)prime;
+  return {(uint32_t)chunk, (uint32_t)magic, l - 1, inv, (float)prime, digits, prime, 0.5f * inv};
 }
 
 // Where the per-dimension entries live: the HBM table (all 620 dimensions) or a window [base, base + count) of it that a
@@ -59,32 +60,41 @@ PT_HD HaltonEntry halton_entry(const HaltonTab& t, uint32_t d) {
   return ldg(&t.global[d]);
 }
 
+// The `digits` base-prime digits of rem < 2^22 (leading zeros included), least significant first, through the reference's
+// float sequence f *= 1/b; r += f * digit (samplers.metal:172-180).
+//   rem / prime: floor(fma(rem, inv, 0.5 inv)) is exact — (rem + 0.5) / prime is at least 0.5 / prime away from an integer,
+//   and the two roundings (inv, the fma) move it by less than ((rem + 0.5) / prime) * 2^-23 < 0.5 / prime.
+//   digit = rem - qf * prime: every term is an integer below 2^22, so the explicit fma is exact (it is not a contraction of
+//   reference arithmetic: the reference computes i % b in integers).
+// Zero digits above the index's leading digit add f * 0 = 0 to r, exactly like not visiting them.
+PT_HD void halton_digits(const HaltonEntry& e, float rem, float& f, float& r) {
+  if (e.digits == 1) {
+    f = f * e.inv;
+    r = r + f * rem;
+    return;
+  }
+  for (uint32_t j = 0; j < e.digits; j++) {
+    const float qf = floorf(__builtin_fmaf(rem, e.inv, e.hinv));
+    const float digit = __builtin_fmaf(-qf, e.primef, rem);
+    f = f * e.inv;
+    r = r + f * digit;
+    rem = qf;
+  }
+}
+
 PT_HD float halton(const HaltonTab& tab, uint32_t i, uint32_t d) {
   const HaltonEntry e = halton_entry(tab, d);
   float f = 1.0f;
   float r = 0.0f;
-  while (i > 0) {
+  for (;;) {
     // q = i / chunk (HaltonEntry); rem = i % chunk holds `digits` base-prime digits
     const uint32_t t = mulhi_u32(e.magic, i);
     const uint32_t q = (t + ((i - t) >> 1)) >> e.shift;
-    float rem = (float)(i - mul_u24(q, e.chunk));  // < 2^22: exact
-    if (e.digits == 1) {
-      f = f * e.inv;
-      r = r + f * rem;
-    } else {
-      // rem / prime for rem < 2^22: floor((rem + 0.5) * inv) is exact — (rem + 0.5) / prime is at least 0.5 / prime away from
-      // an integer and the two roundings (inv, the product) move it by at most (rem / prime) * 2^-23 < 0.5 / prime.
-      // Leading zero digits of the last chunk add f * 0 = 0 to r, exactly like not visiting them.
-      for (uint32_t j = 0; j < e.digits; j++) {
-        const float qf = floorf((rem + 0.5f) * e.inv);
-        const float digit = rem - qf * e.primef;
-        f = f * e.inv;
-        r = r + f * digit;
-        rem = qf;
-      }
-    }
+    halton_digits(e, (float)(i - mul_u24(q, e.chunk)), f, r);  // the remainder is below 2^22: exact
     i = q;
+    if (q < e.chunk) break;  // q is its own remainder: no further division
   }
+  if (i > 0) halton_digits(e, (float)i, f, r);
   return fminf(r, kOneMinusEpsilon);
 }
 

@@ -74,13 +74,14 @@ def test_halton_fp32_division_boundaries_equal_oracle():
     the top of the 32-bit range.  (An fp32 division of the small quotients was tried on top of it: bit-exact, but slower.)"""
     e = emu_lib.EmuScene(scenes.cornell_scene(), make_params(8, 8, 1, 2))
     L = oracle_lib.lib()
-    for d in list(range(0, 64)) + list(range(64, 620, 7)) + [619]:
+    for d in list(range(0, 64)) + list(range(64, 620, 7)) + [37, 53, 302, 303, 619]:  # (37..53: primes 163..251, two divisions)
         p = L.orc_prime(d)
         chunk = p
         while chunk * p < (1 << 22):   # pt_sampler.h make_halton_entry: the largest power below 2^22
             chunk *= p
+        # (chunk - 1, chunk, chunk + 1: the quotient that is / is not its own last remainder — pt_sampler.h stops dividing at q < chunk)
         ks = [1, 2, 3, max(1, (1 << 21) // chunk - 1), max(1, (1 << 21) // chunk), (1 << 21) // chunk + 1, chunk - 1, chunk, chunk + 1,
-              (1 << 32) // chunk - 1, (1 << 32) // chunk]
+              chunk * chunk - 1, chunk * chunk, chunk * chunk + 1, (1 << 32) // chunk - 1, (1 << 32) // chunk]
         # remainders whose digit splits sit on the fp32 rounding boundary: multiples of the prime (+-1) just below the chunk
         rems = [chunk - 1, chunk - p, chunk - p - 1, chunk - p + 1, (chunk // p) * p - 1, p * (p - 1), p * p - 1 if p * p <= chunk else chunk - 1]
         for r in rems:
