@@ -424,7 +424,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
   uint32_t sg = wave_index();
   uint16_t* bin = &lds_bins[threadIdx.x >> 6][0][0];  // this wave's bins: [class][kBinCap] slot numbers within the segment
   while (sg < seg.nseg) {
-    const uint32_t n = seg.active[cur][sg];
+    const uint32_t n = __builtin_amdgcn_readfirstlane(seg.active[cur][sg]);  // (a scalar for the compiler too: the scan loop and the bin counters stay in SGPRs)
     uint32_t n_out = 0, n_shadow = 0;
     // ---- hits are shaded one MATERIAL CLASS per wave pass.  The segment is scanned 64 slots at a time; every slot number goes
     //      to the LDS bin of its hit's class (4 lobe classes + misses); as soon as a bin holds 64 entries they are shaded
@@ -453,26 +453,29 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
         k0 += 64;
       }
       // one pass: a full bin if there is one, else (segment scanned) whatever is left, class by class
+      // (the fill levels are only ever named by constant: they stay in scalar registers)
       uint32_t k = kInvalidRef;
       bool is_miss = false;
       const uint32_t full = cnt0 >= 64 ? 0u : cnt1 >= 64 ? 1u : cnt2 >= 64 ? 2u : cnt3 >= 64 ? 3u : cnt4 >= 64 ? 4u : 5u;
       if (full < 5) {
-        uint32_t& c = full == 0 ? cnt0 : full == 1 ? cnt1 : full == 2 ? cnt2 : full == 3 ? cnt3 : cnt4;
-        c -= 64;
+        uint32_t c = 0;
+        if (full == 0) c = cnt0 -= 64; else if (full == 1) c = cnt1 -= 64; else if (full == 2) c = cnt2 -= 64;
+        else if (full == 3) c = cnt3 -= 64; else c = cnt4 -= 64;
         k = bin[full * kBinCap + c + lane];
         is_miss = full == 4;
       } else {
         if (cnt0 + cnt1 + cnt2 + cnt3 + cnt4 == 0) break;
         // (k0 >= n here) fill the pass from the bins in class order
         uint32_t taken = 0;
-        uint32_t* cs[5] = {&cnt0, &cnt1, &cnt2, &cnt3, &cnt4};
-#pragma unroll
-        for (uint32_t c = 0; c < 5; c++) {
-          const uint32_t take = *cs[c] < 64 - taken ? *cs[c] : 64 - taken;
-          if (lane >= taken && lane < taken + take) { k = bin[c * kBinCap + *cs[c] - take + (lane - taken)]; is_miss = c == 4; }
-          *cs[c] -= take;
-          taken += take;
+#define PT_TAKE_FROM(c, cnt)                                                                                                   \
+        {                                                                                                                      \
+          const uint32_t take = cnt < 64 - taken ? cnt : 64 - taken;                                                           \
+          if (lane >= taken && lane < taken + take) { k = bin[c * kBinCap + cnt - take + (lane - taken)]; is_miss = c == 4; }  \
+          cnt -= take;                                                                                                         \
+          taken += take;                                                                                                       \
         }
+        PT_TAKE_FROM(0, cnt0) PT_TAKE_FROM(1, cnt1) PT_TAKE_FROM(2, cnt2) PT_TAKE_FROM(3, cnt3) PT_TAKE_FROM(4, cnt4)
+#undef PT_TAKE_FROM
       }
       const bool has = k != kInvalidRef && !is_miss;
       const uint32_t i = seg_slot(seg.nseg, sg, k != kInvalidRef ? k : 0u);
