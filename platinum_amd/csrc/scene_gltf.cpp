@@ -27,7 +27,7 @@ namespace ptio {
 [[noreturn]] static void fail(const std::string& m) { throw std::runtime_error(m); }
 
 // ---------------------------------------------------------------------------------------------------------------
-// PNG -> RGBA8 (what stbi_load_from_memory(..., 4) returns for a PNG): all colour types, bit depths 1-16, tRNS, no Adam7
+// PNG -> RGBA8 (what stbi_load_from_memory(..., 4) returns for a PNG): all colour types, bit depths 1-16, tRNS, Adam7
 // ---------------------------------------------------------------------------------------------------------------
 static uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
 
@@ -56,22 +56,39 @@ std::vector<uint8_t> decode_png_rgba8(const uint8_t* data, size_t len, uint32_t*
     p += 12 + (size_t)clen;
   }
   if (!w || !h || w > 32768 || h > 32768) fail("png: bad size");
-  if (interlace) fail("png: Adam7 interlacing is not supported");
+  if (interlace > 1) fail("png: unknown interlace method");
   const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
   if (!channels || !(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) fail("png: unsupported colour type / bit depth");
   const size_t bpp_bits = (size_t)channels * depth;
-  const size_t stride = (w * bpp_bits + 7) / 8;
   const size_t fbpp = std::max<size_t>(1, bpp_bits / 8);  // filter byte distance
-  std::vector<uint8_t> raw((stride + 1) * h);
+  // The image as one pass, or Adam7's seven reduced images (each filtered on its own, stored one after the other)
+  struct Pass { uint32_t x0, dx, y0, dy, pw, ph; };
+  std::vector<Pass> passes;
+  if (!interlace) passes.push_back({0, 1, 0, 1, w, h});
+  else {
+    static const uint32_t xo[7] = {0, 4, 0, 2, 0, 1, 0}, yo[7] = {0, 0, 4, 0, 2, 0, 1}, xs[7] = {8, 8, 4, 4, 2, 2, 1}, ys[7] = {8, 8, 8, 4, 4, 2, 2};
+    for (int k = 0; k < 7; k++) {
+      const uint32_t pw = (w - xo[k] + xs[k] - 1) / xs[k], ph = (h - yo[k] + ys[k] - 1) / ys[k];
+      if (w > xo[k] && h > yo[k] && pw && ph) passes.push_back({xo[k], xs[k], yo[k], ys[k], pw, ph});
+    }
+  }
+  size_t raw_size = 0;
+  for (const Pass& ps : passes) raw_size += ((ps.pw * bpp_bits + 7) / 8 + 1) * ps.ph;
+  std::vector<uint8_t> raw(raw_size);
   {
     uLongf out_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) fail("png: zlib stream is corrupt");
   }
-  std::vector<uint8_t> prev(stride, 0), cur(stride);
   std::vector<uint8_t> out((size_t)w * h * 4);
-  for (uint32_t y = 0; y < h; y++) {
-    const uint8_t ft = raw[y * (stride + 1)];
-    const uint8_t* src = &raw[y * (stride + 1) + 1];
+  size_t raw_at = 0;
+  for (const Pass& ps : passes) {
+  const size_t stride = (ps.pw * bpp_bits + 7) / 8;
+  std::vector<uint8_t> prev(stride, 0), cur(stride);
+  for (uint32_t py = 0; py < ps.ph; py++) {
+    const uint32_t y = ps.y0 + py * ps.dy;
+    const uint8_t ft = raw[raw_at];
+    const uint8_t* src = &raw[raw_at + 1];
+    raw_at += stride + 1;
     for (size_t i = 0; i < stride; i++) {
       const int a = i >= fbpp ? cur[i - fbpp] : 0, b = prev[i], c = i >= fbpp ? prev[i - fbpp] : 0;
       int v = src[i];
@@ -96,8 +113,8 @@ std::vector<uint8_t> decode_png_rgba8(const uint8_t* data, size_t len, uint32_t*
       if (depth == 8) return (uint8_t)v;
       return (uint8_t)(v * (depth == 1 ? 255 : depth == 2 ? 85 : 17));
     };
-    uint8_t* o = &out[(size_t)y * w * 4];
-    for (uint32_t x = 0; x < w; x++, o += 4) {
+    for (uint32_t x = 0; x < ps.pw; x++) {
+      uint8_t* o = &out[((size_t)y * w + ps.x0 + (size_t)x * ps.dx) * 4];
       switch (ctype) {
         case 0: {
           const uint32_t g = sample(x);
@@ -124,6 +141,7 @@ std::vector<uint8_t> decode_png_rgba8(const uint8_t* data, size_t len, uint32_t*
       }
     }
     prev.swap(cur);
+  }
   }
   *w_out = w; *h_out = h;
   return out;
@@ -425,9 +443,21 @@ struct Accessor {
   size_t count = 0, stride = 0;
   int comps = 0, ctype = 0;
   bool normalized = false;
+  // accessor.sparse (fastgltf tools.hpp:529-548): element sp_index[k] is replaced by the k-th packed element of sp_values
+  std::vector<uint32_t> sp_index;
+  const uint8_t* sp_values = nullptr;
+  bool zeros = false;  // no bufferView: the elements that sparse does not replace are zero (glTF 2.0 §3.6.2.3)
   size_t csize() const { return ctype == 5120 || ctype == 5121 ? 1 : ctype == 5122 || ctype == 5123 ? 2 : 4; }
+  const uint8_t* element(size_t i) const {
+    static const uint8_t zero[16] = {0};
+    if (!sp_index.empty()) {
+      const auto it = std::lower_bound(sp_index.begin(), sp_index.end(), (uint32_t)i);
+      if (it != sp_index.end() && *it == i) return sp_values + (size_t)(it - sp_index.begin()) * csize() * (size_t)comps;
+    }
+    return zeros ? zero : base + i * stride;
+  }
   float f(size_t i, int c) const {
-    const uint8_t* p = base + i * stride + (size_t)c * csize();
+    const uint8_t* p = element(i) + (size_t)c * csize();
     switch (ctype) {
       case 5126: { float v; memcpy(&v, p, 4); return v; }
       case 5121: return normalized ? (float)p[0] / 255.0f : (float)p[0];
@@ -439,7 +469,7 @@ struct Accessor {
     }
   }
   uint32_t u(size_t i) const {
-    const uint8_t* p = base + i * stride;
+    const uint8_t* p = element(i);
     switch (ctype) {
       case 5121: return p[0];
       case 5123: { uint16_t v; memcpy(&v, p, 2); return v; }
@@ -450,7 +480,6 @@ struct Accessor {
 };
 Accessor accessor(const Gltf& g, size_t idx, int want_comps) {
   const JV& a = g.item("accessors", idx);
-  if (a.find("sparse")) fail("gltf: sparse accessors are not supported");
   Accessor r;
   r.count = (size_t)a.at("count").u64();
   r.ctype = (int)a.at("componentType").u64();
@@ -458,12 +487,36 @@ Accessor accessor(const Gltf& g, size_t idx, int want_comps) {
   r.comps = type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : 0;
   if (r.comps != want_comps) fail("gltf: accessor has type " + type + ", expected " + std::to_string(want_comps) + " components");
   r.normalized = a.find("normalized") && a.at("normalized").boolean();
-  if (!a.find("bufferView")) fail("gltf: accessor without a bufferView is not supported");
+  const size_t elem = r.csize() * (size_t)r.comps;
+  if (const JV* sp = a.find("sparse")) {
+    const size_t n = (size_t)sp->at("count").u64();
+    const JV& si = sp->at("indices");
+    const JV& sv = sp->at("values");
+    const View iv = buffer_view(g, (size_t)si.at("bufferView").u64()), vv = buffer_view(g, (size_t)sv.at("bufferView").u64());
+    const size_t ioff = si.find("byteOffset") ? (size_t)si.at("byteOffset").u64() : 0, voff = sv.find("byteOffset") ? (size_t)sv.at("byteOffset").u64() : 0;
+    const int ict = (int)si.at("componentType").u64();
+    const size_t isz = ict == 5121 ? 1 : ict == 5123 ? 2 : ict == 5125 ? 4 : 0;
+    if (!isz) fail("gltf: sparse indices must be an unsigned integer type");
+    if (n > r.count || ioff + n * isz > iv.len || voff + n * elem > vv.len) fail("gltf: sparse accessor exceeds its bufferViews");
+    r.sp_index.resize(n);
+    for (size_t k = 0; k < n; k++) {
+      const uint8_t* p = iv.p + ioff + k * isz;
+      uint32_t x = 0;
+      if (isz == 1) x = p[0]; else if (isz == 2) { uint16_t t; memcpy(&t, p, 2); x = t; } else memcpy(&x, p, 4);
+      if (x >= r.count || (k && x <= r.sp_index[k - 1])) fail("gltf: sparse indices must be strictly increasing and below accessor.count");
+      r.sp_index[k] = x;
+    }
+    r.sp_values = vv.p + voff;
+  }
+  if (!a.find("bufferView")) {
+    if (r.sp_index.empty() && r.count) fail("gltf: accessor without a bufferView is not supported");
+    r.zeros = true;
+    return r;
+  }
   const size_t bvi = (size_t)a.at("bufferView").u64();
   const View v = buffer_view(g, bvi);
   const JV& bv = g.item("bufferViews", bvi);
   const size_t off = a.find("byteOffset") ? (size_t)a.at("byteOffset").u64() : 0;
-  const size_t elem = r.csize() * (size_t)r.comps;
   r.stride = bv.find("byteStride") ? (size_t)bv.at("byteStride").u64() : elem;
   if (r.count && off + (r.count - 1) * r.stride + elem > v.len) fail("gltf: accessor exceeds its bufferView");
   r.base = v.p + off;

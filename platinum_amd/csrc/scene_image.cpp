@@ -2,9 +2,10 @@
 // TextureType::HDR (/root/reference/src/loaders/texture.cpp:86-103): OpenEXR through tinyexr's LoadEXR, anything else
 // through stb_image's stbi_loadf (Radiance .hdr).  Both are third-party code vendored by the reference (deps/tinyexr,
 // deps/stb_image); this file restates the parts of their behaviour an environment map needs:
-//   EXR   single-part scanline files, NONE / RLE / ZIPS / ZIP / PIZ compression, HALF / FLOAT / UINT channels, data-window offsets,
-//         either line order; RGBA assembled as LoadEXR does (missing A = 1, a single channel is replicated to all four).
-//         PXR24 / B44 / DWA and tiled or multi-part files are a loud error.
+//   EXR   single-part scanline and tiled files (of a multi-resolution file the full-size level, the one LoadEXR assembles),
+//         NONE / RLE / ZIPS / ZIP / PIZ compression, HALF / FLOAT / UINT channels, data-window offsets, either line order;
+//         RGBA assembled as LoadEXR does (missing A = 1, a single channel is replicated to all four).
+//         PXR24 / B44 / DWA and multi-part or deep files are a loud error.
 //   HDR   "#?RADIANCE" / "#?RGBE", -Y H +X W, flat and new-style RLE scanlines; float = mantissa * 2^(e - 136), alpha 1.
 // Pinned in tests/test_scene_ingestion.py against files written by an independent Python encoder and, where oracle/_ref was
 // built, against the reference's own tinyexr (oracle/_ref/exr2raw).
@@ -282,12 +283,13 @@ std::vector<float> read_exr_rgba(const std::string& path, uint32_t* w_out, uint3
   if (n < 8 || u32(0) != 20000630u) fail("exr: bad magic");
   const uint32_t version = u32(4);
   if ((version & 0xffu) != 2) fail("exr: unsupported version");
-  if (version & 0x200u) fail("exr: tiled files are not supported");
+  const bool tiled = (version & 0x200u) != 0;
   if (version & 0x1800u) fail("exr: deep / multi-part files are not supported");
   size_t p = 8;
   auto cstr = [&](size_t& q) { std::string s; while (q < n && b[q]) s += (char)b[q++]; if (q >= n) fail("exr: truncated header"); q++; return s; };
   std::vector<Channel> channels;
   int compression = -1, line_order = 0;
+  uint32_t tile_w = 0, tile_h = 0, tile_mode = 0;
   int dw[4] = {0, 0, -1, -1};
   for (;;) {
     const std::string name = cstr(p);
@@ -310,6 +312,7 @@ std::vector<float> read_exr_rgba(const std::string& path, uint32_t* w_out, uint3
     } else if (name == "compression") compression = b[p];
     else if (name == "dataWindow") for (int k = 0; k < 4; k++) dw[k] = i32(p + 4 * (size_t)k);
     else if (name == "lineOrder") line_order = b[p];
+    else if (name == "tiles" && size >= 9) { tile_w = u32(p); tile_h = u32(p + 4); tile_mode = b[p + 8]; }
     p += size;
   }
   if (channels.empty() || compression < 0 || dw[2] < dw[0] || dw[3] < dw[1]) fail("exr: incomplete header");
@@ -317,11 +320,12 @@ std::vector<float> read_exr_rgba(const std::string& path, uint32_t* w_out, uint3
   if (line_order > 1) fail("exr: random-y line order is not supported");
   const int64_t W = (int64_t)dw[2] - dw[0] + 1, H = (int64_t)dw[3] - dw[1] + 1;
   if (W <= 0 || H <= 0 || W > 65536 || H > 65536) fail("exr: bad data window");
+  if (tiled && (!tile_w || !tile_h || tile_w > 65536 || tile_h > 65536 || (tile_mode & 0xf) > 2)) fail("exr: tiled file without a valid tile description");
   const int lines_per_block = compression == 3 ? 16 : (compression == 4 ? 32 : 1);
-  const size_t nblocks = (size_t)((H + lines_per_block - 1) / lines_per_block);
-  size_t bytes_per_line = 0;
-  std::vector<size_t> ch_off(channels.size());
-  for (size_t c = 0; c < channels.size(); c++) { ch_off[c] = bytes_per_line; bytes_per_line += (size_t)W * (channels[c].type == 1 ? 2 : 4); }
+  // blocks: scan-line files = groups of lines over the full width; tiled files = the tiles of level (0, 0), which come first in
+  // the offset table of increasing- and decreasing-y files (the further levels of MIPMAP / RIPMAP files are not read)
+  const size_t tiles_x = tiled ? (size_t)((W + tile_w - 1) / tile_w) : 1, tiles_y = tiled ? (size_t)((H + tile_h - 1) / tile_h) : 0;
+  const size_t nblocks = tiled ? tiles_x * tiles_y : (size_t)((H + lines_per_block - 1) / lines_per_block);
   // RGBA assembly as tinyexr's LoadEXR: channels by name; one channel alone fills all four
   int idx[4] = {-1, -1, -1, -1};
   for (size_t c = 0; c < channels.size(); c++) {
@@ -338,13 +342,29 @@ std::vector<float> read_exr_rgba(const std::string& path, uint32_t* w_out, uint3
     uint64_t off;
     memcpy(&off, b + table + 8 * blk, 8);
     if (off + 8 > n) fail("exr: block offset out of range");
-    const int y0 = i32((size_t)off) - dw[1];
-    const uint32_t csize = u32((size_t)off + 4);
-    if (off + 8 + (uint64_t)csize > n) fail("exr: truncated block");
-    if (y0 < 0 || y0 >= H) fail("exr: block outside the data window");
-    const int lines = (int)std::min<int64_t>(lines_per_block, H - y0);
+    int y0, lines;
+    int64_t x0 = 0, bw = W;  // the block's columns
+    size_t hdr = 8;
+    if (tiled) {
+      hdr = 20;
+      if (off + hdr > n) fail("exr: block offset out of range");
+      const int tx = i32((size_t)off), ty = i32((size_t)off + 4);
+      if (i32((size_t)off + 8) != 0 || i32((size_t)off + 12) != 0) fail("exr: the offset table does not start with the full-resolution tiles");
+      if (tx < 0 || ty < 0 || (size_t)tx >= tiles_x || (size_t)ty >= tiles_y) fail("exr: tile outside the data window");
+      x0 = (int64_t)tx * tile_w; bw = std::min<int64_t>(tile_w, W - x0);
+      y0 = (int)((int64_t)ty * tile_h); lines = (int)std::min<int64_t>(tile_h, H - y0);
+    } else {
+      y0 = i32((size_t)off) - dw[1];
+      if (y0 < 0 || y0 >= H) fail("exr: block outside the data window");
+      lines = (int)std::min<int64_t>(lines_per_block, H - y0);
+    }
+    const uint32_t csize = u32((size_t)off + hdr - 4);
+    if (off + hdr + (uint64_t)csize > n) fail("exr: truncated block");
+    size_t bytes_per_line = 0;
+    std::vector<size_t> ch_off(channels.size());
+    for (size_t c = 0; c < channels.size(); c++) { ch_off[c] = bytes_per_line; bytes_per_line += (size_t)bw * (channels[c].type == 1 ? 2 : 4); }
     raw.assign(bytes_per_line * (size_t)lines, 0);
-    const uint8_t* src = b + off + 8;
+    const uint8_t* src = b + off + hdr;
     if (csize == raw.size()) memcpy(raw.data(), src, raw.size());  // stored uncompressed (NONE, or when compression did not pay)
     else if (compression == 1) { if (!exr_unrle(src, csize, raw)) fail("exr: bad RLE data"); exr_unpredict(raw); }
     else if (compression == 2 || compression == 3) {
@@ -352,11 +372,11 @@ std::vector<float> read_exr_rgba(const std::string& path, uint32_t* w_out, uint3
       if (uncompress(raw.data(), &len, src, csize) != Z_OK || len != raw.size()) fail("exr: bad zlib data");
       exr_unpredict(raw);
     } else if (compression == 4) {
-      if (!piz_decompress(src, csize, channels, (int)W, lines, raw)) fail("exr: bad PIZ data");
+      if (!piz_decompress(src, csize, channels, (int)bw, lines, raw)) fail("exr: bad PIZ data");
     } else fail("exr: block size does not match an uncompressed file");
     for (int l = 0; l < lines; l++) {
       const uint8_t* line = &raw[bytes_per_line * (size_t)l];
-      float* dst = &out[(size_t)(y0 + l) * W * 4];
+      float* dst = &out[((size_t)(y0 + l) * W + (size_t)x0) * 4];
       auto value = [&](int c, int64_t x) -> float {
         const uint8_t* q = line + ch_off[(size_t)c];
         switch (channels[(size_t)c].type) {
@@ -365,7 +385,7 @@ std::vector<float> read_exr_rgba(const std::string& path, uint32_t* w_out, uint3
           default: { uint32_t u; memcpy(&u, q + 4 * x, 4); return (float)u; }
         }
       };
-      for (int64_t x = 0; x < W; x++) {
+      for (int64_t x = 0; x < bw; x++) {
         if (single) { const float v = value(0, x); dst[4 * x] = dst[4 * x + 1] = dst[4 * x + 2] = dst[4 * x + 3] = v; }
         else {
           dst[4 * x] = value(idx[0], x); dst[4 * x + 1] = value(idx[1], x); dst[4 * x + 2] = value(idx[2], x);

@@ -100,15 +100,9 @@ def write_reference_scene(json_path, assets, root, envmap=None, next_id=None):
 
 
 # ---- PNG --------------------------------------------------------------------------------------------------------
-def png_bytes(img, palette=None, trns=None, filter_type=None):
-    """Encode an (H, W[, C]) uint8/uint16 array: C = 1 grey, 2 grey+alpha, 3 RGB, 4 RGBA; with `palette` (N,3) the array
-    holds indices (colour type 3).  Filters are cycled per row unless fixed (exercises every unfilter path)."""
-    a = np.asarray(img)
-    if a.ndim == 2:
-        a = a[..., None]
+def _png_filtered(a, depth, filter_type):
+    """Filtered scanlines (filter byte + bytes) of one (H, W, C) image — the whole picture, or one Adam7 pass."""
     h, w, c = a.shape
-    depth = 16 if a.dtype == np.uint16 else 8
-    ctype = 3 if palette is not None else {1: 0, 2: 4, 3: 2, 4: 6}[c]
     raw_rows = a.astype(">u2").tobytes() if depth == 16 else a.astype(np.uint8).tobytes()
     stride = w * c * depth // 8
     bpp = max(1, c * depth // 8)
@@ -134,11 +128,35 @@ def png_bytes(img, palette=None, trns=None, filter_type=None):
         out.append(ft)
         out.extend(enc)
         prev = row
+    return out
+
+
+ADAM7 = ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))  # x0, y0, dx, dy
+
+
+def png_bytes(img, palette=None, trns=None, filter_type=None, interlace=False):
+    """Encode an (H, W[, C]) uint8/uint16 array: C = 1 grey, 2 grey+alpha, 3 RGB, 4 RGBA; with `palette` (N,3) the array
+    holds indices (colour type 3).  Filters are cycled per row unless fixed (exercises every unfilter path).
+    interlace=True writes the seven Adam7 reduced images."""
+    a = np.asarray(img)
+    if a.ndim == 2:
+        a = a[..., None]
+    h, w, c = a.shape
+    depth = 16 if a.dtype == np.uint16 else 8
+    ctype = 3 if palette is not None else {1: 0, 2: 4, 3: 2, 4: 6}[c]
+    if interlace:
+        out = bytearray()
+        for x0, y0, dx, dy in ADAM7:
+            sub = a[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                out.extend(_png_filtered(np.ascontiguousarray(sub), depth, filter_type))
+    else:
+        out = _png_filtered(a, depth, filter_type)
 
     def chunk(t, d):
         return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
 
-    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0))
     if palette is not None:
         png += chunk(b"PLTE", np.asarray(palette, dtype=np.uint8).tobytes())
     if trns is not None:
@@ -339,6 +357,64 @@ def write_exr(path, channels, compression="zip", pixel_type="float", data_window
     table = b"".join(struct.pack("<Q", offsets[y]) for y in sorted(starts))
     with open(path, "wb") as f:
         f.write(hdr + table + body)
+
+
+def write_exr_tiled(path, channels, tile=(32, 16), compression="zip", pixel_type="float", mipmap=False, line_order=0):
+    """Single-part TILED OpenEXR 2.0 (NONE / ZIP), one level or MIPMAP_LEVELS + ROUND_DOWN.  The further levels of a mipmap file hold
+    the constant 7 (a reader that assembled anything but level 0 would show it).  Offset table: level by level, tiles row-major."""
+    names = sorted(channels)
+    h, w = channels[names[0]].shape
+    comp = {"none": 0, "zip": 3}[compression]
+    ptype = {"half": 1, "float": 2}[pixel_type]
+    dt = np.float16 if ptype == 1 else np.float32
+    tx, ty = tile
+
+    def attr(name, typ, data):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(data)) + data
+
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<IB3xII", ptype, 0, 1, 1) for n in names) + b"\0"
+    win = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    hdr = struct.pack("<II", 20000630, 2 | 0x200)
+    hdr += attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([comp]))
+    hdr += attr("dataWindow", "box2i", win) + attr("displayWindow", "box2i", win) + attr("lineOrder", "lineOrder", bytes([line_order]))
+    hdr += attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0))
+    hdr += attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    hdr += attr("tiles", "tiledesc", struct.pack("<IIB", tx, ty, 1 if mipmap else 0)) + b"\0"
+    levels = [(w, h)]
+    if mipmap:
+        n = int(np.floor(np.log2(max(w, h)))) + 1
+        levels = [(max(1, w >> l), max(1, h >> l)) for l in range(n)]
+
+    def pack(raw):
+        if comp == 0:
+            return raw
+        a = np.frombuffer(raw, dtype=np.uint8)
+        inter = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)
+        pred = np.empty_like(inter)
+        pred[0] = inter[0]
+        pred[1:] = (inter[1:] - inter[:-1] + 128 + 256) % 256
+        cb = zlib.compress(pred.astype(np.uint8).tobytes(), 6)
+        return cb if len(cb) < len(raw) else raw
+
+    chunks = []
+    for l, (lw, lh) in enumerate(levels):
+        for j in range((lh + ty - 1) // ty):
+            for i in range((lw + tx - 1) // tx):
+                x0, y0 = i * tx, j * ty
+                x1, y1 = min(lw, x0 + tx), min(lh, y0 + ty)
+                if l == 0:
+                    raw = b"".join(np.ascontiguousarray(channels[n][yy, x0:x1], dtype=dt).tobytes() for yy in range(y0, y1) for n in names)
+                else:
+                    raw = np.full((y1 - y0) * len(names) * (x1 - x0), 7.0, dt).tobytes()
+                data = pack(raw)
+                chunks.append(struct.pack("<iiiiI", i, j, l, l, len(data)) + data)
+    pos = len(hdr) + 8 * len(chunks)
+    table = b""
+    for c in chunks:
+        table += struct.pack("<Q", pos)
+        pos += len(c)
+    with open(path, "wb") as f:
+        f.write(hdr + table + b"".join(chunks))
 
 
 def write_exr_blocks(path, names, w, h, pixel_type, comp_code, lines_per_block, blocks):

@@ -275,6 +275,37 @@ def test_tangents_match_reference_mikktspace_and_fixture(name):
 
 
 # ---- PNG -----------------------------------------------------------------------------------------------------------------
+def test_png_adam7_interlaced_matches_plain_and_the_references_stb_image(tmp_path):
+    """Adam7 (stb_image decodes it, so loaders/texture.cpp does): every pass geometry incl. images narrower / shorter than the
+    8x8 pattern (empty passes), 8- and 16-bit, palette, grey; checked against the array that was encoded, against the same picture
+    written without interlacing, and — where oracle/_ref was built — against the reference's own stb_image v2.30."""
+    rng = np.random.default_rng(8)
+    have_stb = os.path.exists(os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "stbi2raw"))
+    pal = rng.integers(0, 256, (7, 3), dtype=np.uint8)
+    for (h, w) in [(1, 1), (1, 9), (2, 3), (3, 5), (5, 2), (8, 8), (9, 9), (13, 7), (17, 33)]:
+        rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        rgba16 = rng.integers(0, 65536, (h, w, 4), dtype=np.uint16)
+        grey = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        pidx = rng.integers(0, 7, (h, w), dtype=np.uint8)
+        cases = [(rgba, {}, rgba), (rgba16, {}, (rgba16 >> 8).astype(np.uint8)),
+                 (grey, {}, np.stack([grey, grey, grey, np.full_like(grey, 255)], -1)),
+                 (rgba[..., :3], {}, np.concatenate([rgba[..., :3], np.full((h, w, 1), 255, np.uint8)], -1)),
+                 (pidx, {"palette": pal}, np.concatenate([pal[pidx], np.full((h, w, 1), 255, np.uint8)], -1))]
+        for k, (img, kw, want) in enumerate(cases):
+            png = sf.png_bytes(img, interlace=True, **kw)
+            got = scene_io.decode_image_rgba8(png)
+            assert got.shape == (h, w, 4) and np.array_equal(got, want), (h, w, k)
+            assert np.array_equal(got, scene_io.decode_image_rgba8(sf.png_bytes(img, **kw))), (h, w, k)
+            if have_stb:
+                f = tmp_path / f"a7_{h}x{w}_{k}.png"
+                f.write_bytes(png)
+                assert np.array_equal(sf.stbi_reference_rgba(f), got), (h, w, k)
+    bad = bytearray(sf.png_bytes(rng.integers(0, 256, (4, 4, 4), dtype=np.uint8)))
+    bad[8 + 8 + 12] = 2                                    # IHDR interlace method 2 does not exist
+    with pytest.raises(abi.PtamdError, match="png: "):
+        scene_io.decode_image_rgba8(bytes(bad))
+
+
 def test_png_decoder_all_colour_types(tmp_path):
     """Through the importer: a glTF whose base-colour texture is the PNG under test (sRGB type = RGBA8 bytes verbatim)."""
     rng = np.random.default_rng(2)
@@ -475,6 +506,50 @@ def test_gltf_create_scene_nodes_option_and_errors(tmp_path):
         scene_io.SceneFile.empty().import_gltf(str(bad))
 
 
+def test_gltf_sparse_accessors(tmp_path):
+    """accessor.sparse (fastgltf::iterateAccessor substitutes the listed elements, tools.hpp:529-548): positions with two displaced
+    vertices, u8 / u16 index types, a texcoord accessor without a bufferView (zeros + sparse), sparse triangle indices."""
+    base = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [2, 0, 0], [2, 1, 0]], f32)
+    b = sf.GltfBuilder()
+    pos = b.accessor(base, "VEC3")
+    sp_idx = b.view(np.array([1, 4], np.uint8).tobytes())
+    sp_val = b.view(np.array([[1, 0, 5], [2, 0, 7]], f32).tobytes())
+    b.doc["accessors"][pos]["sparse"] = {"count": 2, "indices": {"bufferView": sp_idx, "componentType": 5121},
+                                          "values": {"bufferView": sp_val}}
+    uv_idx = b.view(b"\0\0" + np.array([2, 5], np.uint16).tobytes())        # (byteOffset 2 into the view)
+    uv_val = b.view(np.array([[0.25, 0.5], [0.75, 1.0]], f32).tobytes())
+    b.doc["accessors"].append({"componentType": 5126, "count": 6, "type": "VEC2",
+                               "sparse": {"count": 2, "indices": {"bufferView": uv_idx, "byteOffset": 2, "componentType": 5123},
+                                          "values": {"bufferView": uv_val}}})
+    uv = len(b.doc["accessors"]) - 1
+    ind = b.accessor(np.array([0, 1, 2, 1, 3, 2, 0, 0, 0], np.uint16), "SCALAR", component=5123)
+    ii = b.view(np.array([6, 7, 8], np.uint32).tobytes())
+    iv = b.view(np.array([1, 4, 5], np.uint16).tobytes())
+    b.doc["accessors"][ind]["sparse"] = {"count": 3, "indices": {"bufferView": ii, "componentType": 5125}, "values": {"bufferView": iv}}
+    b.doc["meshes"].append({"primitives": [{"attributes": {"POSITION": pos, "TEXCOORD_0": uv}, "indices": ind}]})
+    b.doc["nodes"].append({"mesh": 0})
+    b.doc["scenes"].append({"nodes": [0]})
+    path = str(tmp_path / "sparse.glb")
+    b.write(path, glb=True)
+    sc = scene_io.SceneFile.empty().import_gltf(path)
+    sc.add_camera((0, 0, 3), (0, 0, 0))
+    (p, vd, idx, _), = snap_meshes(sc.snapshot().struct)
+    want = base.copy(); want[1] = (1, 0, 5); want[4] = (2, 0, 7)
+    assert np.array_equal(p[:, :3], want)
+    wuv = np.zeros((6, 2), f32); wuv[2] = (0.25, 0.5); wuv[5] = (0.75, 1.0)
+    assert np.array_equal(vd[:, 8:10], wuv)
+    assert idx.tolist() == [0, 1, 2, 1, 3, 2, 1, 4, 5]
+    # indices out of order / beyond the accessor are rejected
+    b.doc["accessors"][pos]["sparse"]["indices"]["bufferView"] = b.view(np.array([4, 1], np.uint8).tobytes())
+    b.write(path, glb=True)
+    with pytest.raises(abi.PtamdError, match="sparse indices must be strictly increasing"):
+        scene_io.SceneFile.empty().import_gltf(path)
+    b.doc["accessors"][pos]["sparse"]["indices"]["bufferView"] = b.view(np.array([1, 6], np.uint8).tobytes())
+    b.write(path, glb=True)
+    with pytest.raises(abi.PtamdError, match="sparse indices must be strictly increasing and below"):
+        scene_io.SceneFile.empty().import_gltf(path)
+
+
 # ---- environment files: OpenEXR and Radiance HDR ------------------------------------------------------------------------
 def _env_pixels(sc):
     s = sc.snapshot().struct
@@ -499,6 +574,60 @@ def test_exr_environment_reader(tmp_path, compression, ptype):
     assert got.shape == (h, w, 4) and got.tobytes() == want.tobytes()
     if os.path.exists(sf.EXR2RAW_PATH):  # the reference's tinyexr reads the same file to the same bits
         assert sf.tinyexr_reference_rgba(path, str(tmp_path)).tobytes() == got.tobytes()
+
+
+@pytest.mark.parametrize("compression,ptype,mipmap", [("zip", "float", False), ("none", "half", False), ("zip", "half", True), ("none", "float", True)])
+def test_exr_tiled_reader(tmp_path, compression, ptype, mipmap):
+    """Tiled files (LoadEXR assembles the tiles of the full-size level, tinyexr.h:6374-6440): edge tiles narrower / lower than the tile
+    size, a multi-resolution file whose further levels must be ignored; the same bits as the reference's tinyexr where it was built."""
+    rng = np.random.default_rng(41)
+    h, w = 45, 70
+    dt = np.float16 if ptype == "half" else f32
+    ch = {n: (rng.random((h, w)) * 30.0).astype(dt).astype(f32) for n in "RGB"}
+    want = np.stack([ch["R"], ch["G"], ch["B"], np.ones((h, w), f32)], -1)
+    path = str(tmp_path / "tiled.exr")
+    sf.write_exr_tiled(path, ch, (32, 16), compression, ptype, mipmap)
+    sc = scene_io.SceneFile.empty()
+    sc.load_environment(path)
+    sc.add_camera((0, 0, 3), (0, 0, 0))
+    got = _env_pixels(sc)
+    assert got.shape == (h, w, 4) and got.tobytes() == want.tobytes()
+    if os.path.exists(sf.EXR2RAW_PATH):
+        assert sf.tinyexr_reference_rgba(path, str(tmp_path)).tobytes() == got.tobytes()
+
+
+def test_exr_tiled_piz_fixture_written_and_read_by_the_references_tinyexr():
+    """tests/golden/exr_piz_tiled_fixture.exr: a 70x45 RGB half file in 32x16 PIZ tiles ENCODED by the reference's tinyexr
+    (oracle/_ref/exrwrite … 32 16); the .npz holds what its LoadEXR reads back (tools/make_golden.py)."""
+    g = np.load(os.path.join(G, "exr_piz_tiled_fixture.npz"))
+    sc = scene_io.SceneFile.empty()
+    sc.load_environment(os.path.join(G, "exr_piz_tiled_fixture.exr"))
+    sc.add_camera((0, 0, 3), (0, 0, 0))
+    got = _env_pixels(sc)
+    assert got.shape == g["rgba"].shape and got.tobytes() == g["rgba"].tobytes()
+
+
+def test_exr_tiled_errors(tmp_path):
+    rng = np.random.default_rng(42)
+    ch = {n: rng.random((20, 24)).astype(f32) for n in "RGB"}
+    path = str(tmp_path / "t.exr")
+    sf.write_exr_tiled(path, ch, (16, 16), "none", "float")
+    blob = bytearray(open(path, "rb").read())
+    first = int.from_bytes(blob[blob.index(b"tiledesc") + 9 + 4 + 9 + 1:][:8], "little")   # offset-table entry 0 (after the header's final NUL)
+    bad = bytearray(blob); bad[first + 8:first + 12] = (1).to_bytes(4, "little")              # level_x = 1
+    open(path, "wb").write(bad)
+    sc = scene_io.SceneFile.empty()
+    with pytest.raises(abi.PtamdError, match="does not start with the full-resolution tiles"):
+        sc.load_environment(path)
+    bad = bytearray(blob); bad[first:first + 4] = (9).to_bytes(4, "little")                   # tile_x beyond the window
+    open(path, "wb").write(bad)
+    with pytest.raises(abi.PtamdError, match="tile outside the data window"):
+        sc.load_environment(path)
+    bad = bytearray(blob); i = bad.index(b"tiledesc") + 9 + 4
+    bad[i:i + 4] = (0).to_bytes(4, "little")                                                 # tile width 0
+    open(path, "wb").write(bad)
+    with pytest.raises(abi.PtamdError, match="valid tile description"):
+        sc.load_environment(path)
 
 
 def test_exr_channel_assembly_window_and_line_order(tmp_path):

@@ -15,6 +15,7 @@ as small fixtures under tests/golden/.  Re-running must reproduce the files bit-
   scene_fixture/mini.*    a scene.json + _data.bin pair in the reference's format (tests/scene_formats.py restates saveToFile)
   exr_piz_fixture.exr/npz a 96x48 RGB half PIZ OpenEXR ENCODED by the reference's tinyexr (oracle/_ref/exrwrite) and the RGBA floats its
                           LoadEXR decodes from it (oracle/_ref/exr2raw)
+  exr_piz_tiled_fixture.* the same for a 70x45 file in 32x16 PIZ tiles (oracle/_ref/exrwrite … 32 16)
   jpeg_stb_fixture.npz    nine small JPEG files (baseline / progressive, 4:4:4 / 4:2:2 / 4:2:0, grey, CMYK, restart markers) and the RGBA8
                           the reference's vendored stb_image (oracle/_ref/stbi2raw) decodes from each
   n3_textured_golden.npz  scenes.textured_scene() (textures, normal map, cut-outs, environment), 96x54, 6 bounces: accumulator
@@ -92,6 +93,11 @@ if os.path.exists(exrwrite) and os.path.exists(exr2raw):
         env.astype(np.float32).tofile(os.path.join(td, "in.f32"))
         subprocess.check_call([exrwrite, os.path.join(td, "in.f32"), "96", "48", "3", "half", "piz", os.path.join(G, "exr_piz_fixture.exr")])
         np.savez_compressed(os.path.join(G, "exr_piz_fixture.npz"), rgba=sf.tinyexr_reference_rgba(os.path.join(G, "exr_piz_fixture.exr"), td))
+        # ... and the same encoder writing 32x16 TILES (edge tiles 6 wide / 13 high)
+        env2 = (scenes.sky_environment(70, 45, sun=(20, 8), sun_radiance=150.0)[..., :3] + np.random.default_rng(77).random((45, 70, 3)) * 0.25).astype(np.float32)
+        env2.tofile(os.path.join(td, "in2.f32"))
+        subprocess.check_call([exrwrite, os.path.join(td, "in2.f32"), "70", "45", "3", "half", "piz", os.path.join(G, "exr_piz_tiled_fixture.exr"), "32", "16"])
+        np.savez_compressed(os.path.join(G, "exr_piz_tiled_fixture.npz"), rgba=sf.tinyexr_reference_rgba(os.path.join(G, "exr_piz_tiled_fixture.exr"), td))
 else:
     print("oracle/_ref/exrwrite not built: exr_piz_fixture left as is")
 # ---- N4: JPEG files (encoded by PIL / libjpeg: test infrastructure) and the RGBA8 the REFERENCE's stb_image decodes from them ----
