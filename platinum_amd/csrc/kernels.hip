@@ -374,6 +374,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
   __shared__ float lds_Eavg[kLutEavg];
   __shared__ float lds_EavgMs[kLutEavgMs * kLutEavgMs];
   __shared__ uint16_t lds_bins[kShadeBlock / 64][5][kBinCap];  // per wave: slot numbers by material class (+ misses), 1.25 KB
+  __shared__ uint32_t lds_bin_tri[kShadeBlock / 64][5][kBinCap]; // ... and the triangle hit there: the pass starts its ShadeRec load with the state gather
 #if PT_SHADE_LDS_E
   __shared__ float lds_E[kLutE * kLutE];
 #endif
@@ -423,6 +424,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
   // time the later bounces are reached, so a static deal would leave waves idle at the end of every launch)
   uint32_t sg = wave_index();
   uint16_t* bin = &lds_bins[threadIdx.x >> 6][0][0];  // this wave's bins: [class][kBinCap] slot numbers within the segment
+  uint32_t* bin_tri = &lds_bin_tri[threadIdx.x >> 6][0][0];
   while (sg < seg.nseg) {
     const uint32_t n = __builtin_amdgcn_readfirstlane(seg.active[cur][sg]);  // (a scalar for the compiler too: the scan loop and the bin counters stay in SGPRs)
     uint32_t n_out = 0, n_shadow = 0;
@@ -436,8 +438,9 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
       while (k0 < n && cnt0 < 64 && cnt1 < 64 && cnt2 < 64 && cnt3 < 64 && cnt4 < 64) {
         const uint32_t k = k0 + lane;
         uint32_t cls = 5;  // no entry
+        uint32_t w = 0;
         if (k < n) {
-          const uint32_t w = f2u(hit[seg_slot(seg.nseg, sg, k)].w);
+          w = f2u(hit[seg_slot(seg.nseg, sg, k)].w);
           cls = w == kInvalidRef ? 4u : (w >> 28) & 3u;
           if (cls == 4u && S.env_texture < 0) cls = 5u;  // a miss without an environment adds nothing (defs.metal:21)
         }
@@ -447,6 +450,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
           const uint32_t at = cls == 0 ? cnt0 + wave_prefix(m0) : cls == 1 ? cnt1 + wave_prefix(m1) : cls == 2 ? cnt2 + wave_prefix(m2)
                             : cls == 3 ? cnt3 + wave_prefix(m3) : cnt4 + wave_prefix(m4);
           bin[cls * kBinCap + at] = (uint16_t)k;
+          bin_tri[cls * kBinCap + at] = w & kHitTriMask;
         }
         cnt0 += (uint32_t)__popcll(m0); cnt1 += (uint32_t)__popcll(m1); cnt2 += (uint32_t)__popcll(m2);
         cnt3 += (uint32_t)__popcll(m3); cnt4 += (uint32_t)__popcll(m4);
@@ -454,7 +458,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
       }
       // one pass: a full bin if there is one, else (segment scanned) whatever is left, class by class
       // (the fill levels are only ever named by constant: they stay in scalar registers)
-      uint32_t k = kInvalidRef;
+      uint32_t k = kInvalidRef, tri = 0;
       bool is_miss = false;
       const uint32_t full = cnt0 >= 64 ? 0u : cnt1 >= 64 ? 1u : cnt2 >= 64 ? 2u : cnt3 >= 64 ? 3u : cnt4 >= 64 ? 4u : 5u;
       if (full < 5) {
@@ -462,6 +466,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
         if (full == 0) c = cnt0 -= 64; else if (full == 1) c = cnt1 -= 64; else if (full == 2) c = cnt2 -= 64;
         else if (full == 3) c = cnt3 -= 64; else c = cnt4 -= 64;
         k = bin[full * kBinCap + c + lane];
+        tri = bin_tri[full * kBinCap + c + lane];
         is_miss = full == 4;
       } else {
         if (cnt0 + cnt1 + cnt2 + cnt3 + cnt4 == 0) break;
@@ -470,7 +475,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
 #define PT_TAKE_FROM(c, cnt)                                                                                                   \
         {                                                                                                                      \
           const uint32_t take = cnt < 64 - taken ? cnt : 64 - taken;                                                           \
-          if (lane >= taken && lane < taken + take) { k = bin[c * kBinCap + cnt - take + (lane - taken)]; is_miss = c == 4; }  \
+          if (lane >= taken && lane < taken + take) { k = bin[c * kBinCap + cnt - take + (lane - taken)]; tri = bin_tri[c * kBinCap + cnt - take + (lane - taken)]; is_miss = c == 4; }  \
           cnt -= take;                                                                                                         \
           taken += take;                                                                                                       \
         }
@@ -509,7 +514,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
         in.dim = (meta & kMetaDimMask) + 1;  // +1: the alpha-test payload `ir` drawn before intersect (kernel.metal:510)
         in.bounce = bounce;
         in.t = h4.x; in.u = h4.y; in.v = h4.z;
-        in.tri = f2u(h4.w) & kHitTriMask;
+        in.tri = tri;
         ShadeGeom g;
         ShadingContext sc;
         shade_geometry(S, in, g, sc);
