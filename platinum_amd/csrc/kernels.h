@@ -54,7 +54,7 @@ void launch_gmon(hipStream_t s, vec4* acc, const vec4* buckets, uint32_t npixels
 void launch_postprocess(hipStream_t s, const vec4* acc, uint32_t* rgba8, uint32_t W, uint32_t H, const PostConstants& pc);
 void launch_fold_counters(hipStream_t s, const BatchCounters* ctr, Totals* tot, Segments seg, bool counted);
 void launch_shade_records(hipStream_t s, const DeviceScene& S, ShadeRec* out);
-void launch_light_records(hipStream_t s, const DeviceScene& S, LightRec* out);
+void launch_light_records(hipStream_t s, const DeviceScene& S, LightRec* out, float* cdf);
 void launch_hit_records(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, const vec4* hit, Segments seg,
                         pt_hit_record* out);
 

@@ -416,6 +416,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
 #endif
   T.halton = HaltonTab{S.halton, lds_halton, halton_base, halton_count};
   T.lights = lights_in_lds ? lds_lights : S.light_recs;
+  T.light_cdf = S.light_cdf;
   T.lights_lds = lights_in_lds ? 1 : 0;
 
   const uint32_t lane = wave_lane();
@@ -781,9 +782,9 @@ __global__ void __launch_bounds__(kBlock) k_fold_counters(const BatchCounters* _
 }
 
 // one LightRec per area light (once per render)
-__global__ void __launch_bounds__(kBlock) k_light_records(DeviceScene S, LightRec* __restrict__ out) {
+__global__ void __launch_bounds__(kBlock) k_light_records(DeviceScene S, LightRec* __restrict__ out, float* __restrict__ cdf) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i < S.lightCount) out[i] = make_light_rec(S, S.lights[i]);
+  if (i < S.lightCount) { out[i] = make_light_rec(S, S.lights[i]); cdf[i] = S.lights[i].cumulativePower; }
 }
 
 // one ShadeRec per flattened triangle, in tris[] order (once per render, after the BVH build)
@@ -884,8 +885,8 @@ void launch_fold_counters(hipStream_t s, const BatchCounters* ctr, Totals* tot, 
 void launch_shade_records(hipStream_t s, const DeviceScene& S, ShadeRec* out) {
   if (S.tri_count) hipLaunchKernelGGL(k_shade_records, dim3((S.tri_count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, S, out);
 }
-void launch_light_records(hipStream_t s, const DeviceScene& S, LightRec* out) {
-  if (S.lightCount) hipLaunchKernelGGL(k_light_records, dim3((S.lightCount + kBlock - 1) / kBlock), dim3(kBlock), 0, s, S, out);
+void launch_light_records(hipStream_t s, const DeviceScene& S, LightRec* out, float* cdf) {
+  if (S.lightCount) hipLaunchKernelGGL(k_light_records, dim3((S.lightCount + kBlock - 1) / kBlock), dim3(kBlock), 0, s, S, out, cdf);
 }
 void launch_hit_records(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, const vec4* hit, Segments seg,
                         pt_hit_record* out) {

@@ -173,6 +173,7 @@ struct DeviceScene {
   const TriRec* tris;
   const ShadeRec* shade_recs;  // tri_count records, same order as tris[]
   const LightRec* light_recs;  // lightCount records, same order as lights[]
+  const float* light_cdf;      // lightCount values: AreaLight::cumulativePower on its own (what sampleLightPower's binary search reads)
   uint32_t tri_count;
   uint32_t root_ref;       // kLeafBit|0 for a single-triangle scene, the root's node index otherwise, kInvalidRef when empty
   const InstanceTrav* inst_trav;  // two-level structure only (two_level != 0): root_ref is the TLAS root, tris[] is in flattening order

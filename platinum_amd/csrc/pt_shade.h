@@ -156,12 +156,13 @@ struct ShadeTables {
   LutSet luts;
   HaltonTab halton;
   const LightRec* lights;
+  const float* light_cdf;  // table in HBM (more than the staged 64 lights): the search reads this 4-byte-stride copy, not the 128-byte records
   int lights_lds;
 };
-PT_HD ShadeTables shade_tables(const DeviceScene& S) { return {S.luts, halton_table(S.halton), S.light_recs, 0}; }
+PT_HD ShadeTables shade_tables(const DeviceScene& S) { return {S.luts, halton_table(S.halton), S.light_recs, S.light_cdf, 0}; }
 PT_HD LightRec load_light(const ShadeTables& T, uint32_t i) { return T.lights_lds ? T.lights[i] : ldg(&T.lights[i]); }
 PT_HD float light_cumulative_power(const ShadeTables& T, uint32_t i) {
-  return T.lights_lds ? T.lights[i].cumulativePower : ldg(&T.lights[i].cumulativePower);
+  return T.lights_lds ? T.lights[i].cumulativePower : ldg(&T.light_cdf[i]);
 }
 
 // kernel.metal:20-25 rayDirToUv, :27-34 uvToRayDir

@@ -370,8 +370,10 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   S.shade_recs = r->shade_recs.p;
   launch_shade_records(r->stream, S, r->shade_recs.p);
   PT_HIP(r->light_recs.alloc(std::max<size_t>(1, r->lights.size())));
+  PT_HIP(r->light_cdf.alloc(std::max<size_t>(1, r->lights.size())));
   S.light_recs = r->light_recs.p;
-  launch_light_records(r->stream, S, r->light_recs.p);
+  S.light_cdf = r->light_cdf.p;
+  launch_light_records(r->stream, S, r->light_recs.p, r->light_cdf.p);
   PT_HIP(r->scene_d.upload(std::vector<DeviceScene>(1, S)));  // k_shade reads the table from memory (scalar loads)
 
   // ---- wavefront buffers ----

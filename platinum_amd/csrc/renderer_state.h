@@ -84,6 +84,7 @@ struct pt_renderer {
   DevBuf<DeviceScene> scene_d;
   DevBuf<ShadeRec> shade_recs;
   DevBuf<LightRec> light_recs;
+  DevBuf<float> light_cdf;
   DevBuf<InstanceTrav> inst_trav;   // two-level structure only
   bool two_level = false;
   int two_level_override = -1;      // $PTAMD_TWO_LEVEL: 0 / 1 force the choice, -1 = by instancing factor
@@ -141,7 +142,7 @@ struct pt_renderer {
 
   void free_scene() {
     positions.release(); vdata.release(); indices.release(); slots.release(); meshes.release(); instances.release();
-    materials.release(); lights_d.release(); tex_pixels.release(); textures.release(); env_alias_d.release(); scene_d.release(); shade_recs.release(); light_recs.release();
+    materials.release(); lights_d.release(); tex_pixels.release(); textures.release(); env_alias_d.release(); scene_d.release(); shade_recs.release(); light_recs.release(); light_cdf.release();
     if (bvh.nodes) (void)hipFree(bvh.nodes);
     if (bvh.tris) (void)hipFree(bvh.tris);
     if (bvh.mesh_trav) (void)hipFree(bvh.mesh_trav);

@@ -26,6 +26,7 @@ struct Emu {
   std::vector<TriRec> tris;
   std::vector<ShadeRec> shade_recs;
   std::vector<LightRec> light_recs;
+  std::vector<float> light_cdf;
   std::vector<BvhNode> nodes;
   DeviceScene S{};
   pt_render_params params{};
@@ -301,6 +302,8 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
   e->light_recs.resize(e->hs.lights.size());
   for (size_t i = 0; i < e->hs.lights.size(); i++) e->light_recs[i] = make_light_rec(S, e->hs.lights[i]);
   S.light_recs = e->light_recs.data();
+  for (auto& l : e->hs.lights) e->light_cdf.push_back(l.cumulativePower);
+  S.light_cdf = e->light_cdf.data();
   Lut* ls[6] = {&S.luts.E, &S.luts.Eavg, &S.luts.EMs, &S.luts.EavgMs, &S.luts.ETransIn, &S.luts.ETransOut};
   for (int i = 0; i < 6; i++) { ls[i]->w = hdr[4 * i]; ls[i]->h = hdr[4 * i + 1]; ls[i]->depth = hdr[4 * i + 2]; ls[i]->d = e->lut.data() + hdr[4 * i + 3]; }
   S.camera = e->hs.constants.camera; S.idt = e->hs.idt; S.width = p->width; S.height = p->height;
