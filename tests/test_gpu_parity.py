@@ -83,6 +83,30 @@ def test_per_bounce_hit_ids_and_radiance(gpu_renderer, name, integrator, bounces
         assert np.array_equal(rg.view(np.uint32), rc.view(np.uint32)), "radiance not bit-identical"
 
 
+@pytest.mark.parametrize("integrator", [abi.INTEGRATOR_MIS, abi.INTEGRATOR_SIMPLE])
+def test_fifty_bounces_reach_the_end_of_the_sampler_table(gpu_renderer, integrator):
+    """max_bounces = 50 (kernel.metal:5) inside a CLOSED glass-sphere Cornell box: the white walls have albedo 1, so roulette lets
+    paths live; the last bounces draw Halton dimensions around 600 of the 620 — far beyond the window k_shade stages in LDS — and the
+    per-bounce counters are used up to index 49."""
+    sc = _scene("cornell_sphere")
+    # close the open +z face with a white wall and put the camera inside: nothing escapes
+    wall = sc.add_mesh(scenes.plane(10.0))
+    sc.add_instance(wall, scenes.Transform(translation=(0, 5, 5), rotation=(-np.pi / 2, 0, 0)), [scenes.Material(base_color=(1, 1, 1, 1))])
+    sc.set_camera(scenes.Camera.with_focal_length(20.0), scenes.Transform(translation=(0, 5, 4.5), target=(0, 4, 0), track=True))
+    w, h = 64, 36
+    p = _start(gpu_renderer, sc, w, h, 2, 50, integrator=integrator)
+    o = oracle_lib.OracleScene(sc, p)
+    rg, hg = gpu_renderer.debugSample(1)
+    rc, hc = o.debug_sample(1)
+    assert np.array_equal(hg, hc) and _same_bits_or_both_nan(rg, rc)
+    alive = (hg.reshape(50, h * w, 2)[:, :, 0] >= 0).sum(1)
+    assert alive[49] > 0, alive            # some paths really are that long
+    gpu_renderer.render(0)
+    assert _same_bits_or_both_nan(gpu_renderer.readbackAccumulator(), o.render(0, 2))
+    with pytest.raises(abi.PtamdError, match="max_bounces must be 1..50"):
+        gpu_renderer.startRender(sc, (w, h), 1, max_bounces=51)
+
+
 def test_accumulator_matches_oracle_c1_small(gpu_renderer):
     """C1 (Cornell, 4 bounces) at reduced size/spp: running-mean accumulator, several batches."""
     sc = _scene("cornell")
