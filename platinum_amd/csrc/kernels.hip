@@ -345,7 +345,7 @@ k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments se
 // Persistent grid sized for the kernel's occupancy (launch_shade); wave w shades segments w, w + P, ...
 // Per block, once: the read-mostly tables every hit touches are staged in LDS — the Halton entries of the dimensions
 // this bounce can reach (5 + 7b .. 15 + 12b: raygen consumes 4, every bounce 7 to 12), the area-light table (binary
-// search + one record per NEE sample) and the E_avg / E_ms_avg energy tables (+ the 64 KB E table with PT_SHADE_LDS_E).
+// search + one record per NEE sample) and the E_avg / E_ms_avg energy tables.
 // Per hit: geometry + material + BSDF set-up, then next-event estimation whose shadow record is compacted into the shadow
 // queue right away, then the BSDF sample / throughput / roulette and the compaction of the survivor.  NEE before the
 // sample (each random number is addressed by its dimension, so the order does not matter) means the shadow record is
@@ -355,9 +355,6 @@ k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments se
 #endif
 #ifndef PT_SHADE_BLOCK
 #define PT_SHADE_BLOCK 256
-#endif
-#ifndef PT_SHADE_LDS_E
-#define PT_SHADE_LDS_E 0
 #endif
 constexpr uint32_t kShadeBlock = PT_SHADE_BLOCK;
 constexpr uint32_t kShadeHalton = 128;  // staged Halton window (entries); dimensions beyond it are read from HBM
@@ -375,9 +372,6 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
   __shared__ float lds_EavgMs[kLutEavgMs * kLutEavgMs];
   __shared__ uint16_t lds_bins[kShadeBlock / 64][5][kBinCap];  // per wave: slot numbers by material class (+ misses), 1.25 KB
   __shared__ uint32_t lds_bin_tri[kShadeBlock / 64][5][kBinCap]; // ... and the triangle hit there: the pass starts its ShadeRec load with the state gather
-#if PT_SHADE_LDS_E
-  __shared__ float lds_E[kLutE * kLutE];
-#endif
   const uint32_t halton_base = 5u + 7u * bounce;
   uint32_t halton_count = 11u + 5u * bounce;
   if (halton_base >= (uint32_t)kHaltonDims) halton_count = 0;
@@ -395,13 +389,6 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
     }
     for (uint32_t i = threadIdx.x; i < (uint32_t)kLutEavg; i += kShadeBlock) lds_Eavg[i] = ldg(&S.luts.Eavg.d[i]);
     for (uint32_t i = threadIdx.x; i < (uint32_t)(kLutEavgMs * kLutEavgMs); i += kShadeBlock) lds_EavgMs[i] = ldg(&S.luts.EavgMs.d[i]);
-#if PT_SHADE_LDS_E
-    {
-      const uint4* es = reinterpret_cast<const uint4*>(S.luts.E.d);
-      uint4* ed = reinterpret_cast<uint4*>(lds_E);
-      for (uint32_t i = threadIdx.x; i < (uint32_t)(kLutE * kLutE / 4); i += kShadeBlock) ed[i] = ldg(&es[i]);
-    }
-#endif
   }
   __syncthreads();
   ShadeTables T;
@@ -411,9 +398,6 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
   T.luts.EavgMs = Lut{lds_EavgMs, kLutEavgMs, kLutEavgMs, 1, 1};
   T.luts.ETransIn = Lut{S.luts.ETransIn.d, S.luts.ETransIn.w, S.luts.ETransIn.h, S.luts.ETransIn.depth, 0};
   T.luts.ETransOut = Lut{S.luts.ETransOut.d, S.luts.ETransOut.w, S.luts.ETransOut.h, S.luts.ETransOut.depth, 0};
-#if PT_SHADE_LDS_E
-  T.luts.E = Lut{lds_E, kLutE, kLutE, 1, 1};
-#endif
   T.halton = HaltonTab{S.halton, lds_halton, halton_base, halton_count};
   T.lights = lights_in_lds ? lds_lights : S.light_recs;
   T.light_cdf = S.light_cdf;
