@@ -63,7 +63,8 @@ public:
   Renderer& operator=(const Renderer&) = delete;
   ~Renderer() { if (m_pt) pt_destroy(m_pt); }
 
-  // renderer_pt.cpp:113-197 steady state: one more sample of every pixel is enqueued; does not wait.
+  // renderer_pt.cpp:113-197 steady state: one more sample of every pixel is enqueued (on EVERY device of a group: N samples);
+  // does not wait.
   void render() {
     if (!m_pt || !m_started) return;
     check(pt_render_step(m_pt, 1));

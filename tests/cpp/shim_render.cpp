@@ -1,7 +1,7 @@
 // TEST PROGRAM (tests/): a C++ host driving libptamd.so the way the reference's frontend drives pt::renderer_pt::Renderer
 // (frontend/windows/pt_viewport.cpp:539-548 startRender, frontend.cpp:207-210 render() once per frame, status() polled, :711 present,
 // readback for export) — through include/ptamd_renderer.hpp, whose members carry the reference's names.
-//   shim_render scene.json W H spp bounces out_prefix [gmon_buckets]
+//   shim_render scene.json W H spp bounces out_prefix [gmon_buckets [devices]]     devices: e.g. 0,0 = a device group (two logical shards on GPU 0)
 // loads the scene file with the library's own reader (pt_scene_load_json, the reference's scene.json + _data.bin format), renders
 // one sample per render() call until Status_Done, and writes <out_prefix>.acc (W*H*4 float), <out_prefix>.rgba (W*H*4 bytes:
 // readbackRenderTarget) and <out_prefix>.present (the same image copied back from the device pointer of presentRenderTarget).
@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -28,12 +29,16 @@ static bool write_file(const std::string& path, const void* data, size_t bytes) 
 }
 
 int main(int argc, char** argv) {
-  if (argc < 7) { fprintf(stderr, "usage: shim_render scene.json W H spp bounces out_prefix [gmon_buckets]\n"); return 2; }
+  if (argc < 7) { fprintf(stderr, "usage: shim_render scene.json W H spp bounces out_prefix [gmon_buckets [devices]]\n"); return 2; }
   const uint32_t W = (uint32_t)atoi(argv[2]), H = (uint32_t)atoi(argv[3]), spp = (uint32_t)atoi(argv[4]), bounces = (uint32_t)atoi(argv[5]);
   const std::string out = argv[6];
   const uint32_t buckets = argc > 7 ? (uint32_t)atoi(argv[7]) : 0;
 
-  Renderer renderer(0);                                  // never throws: a failure is printed and leaves the object blocked
+  std::vector<int> devices;
+  if (argc > 8) for (const char* p = argv[8]; *p; p++) if (*p >= '0' && *p <= '9') devices.push_back(*p - '0');
+  // never throws: a failure is printed and leaves the object blocked
+  const std::unique_ptr<Renderer> holder = devices.empty() ? std::make_unique<Renderer>(0) : std::make_unique<Renderer>(devices);
+  Renderer& renderer = *holder;
   if (!renderer.ok()) return renderer.status() == Renderer::Status_Blocked ? 3 : 5;
 
   pt_scene* scene = nullptr;
@@ -60,10 +65,12 @@ int main(int argc, char** argv) {
     if (!(renderer.status() & Renderer::Status_Busy)) return 5;
     renderer.render();
     if (!renderer.ok()) return 4;
-    if (++frames > spp) return 5;                         // exactly one sample per call
+    if (++frames > spp) return 5;
   }
+  // exactly one sample per call and device: a group of N devices advances N samples per render()
+  const uint32_t members = devices.empty() ? 1u : (uint32_t)devices.size();
   const auto progress = renderer.renderProgress();
-  if (progress.first != spp || progress.second != spp || frames != spp) return 5;
+  if (progress.first != spp || progress.second != spp || frames != (spp + members - 1) / members) return 5;
   if (!(renderer.status() & Renderer::Status_Ready)) return 5;
 
   const std::vector<float> acc = renderer.readbackAccumulator();

@@ -57,6 +57,20 @@ def test_cpp_host_without_a_gpu_reports_and_stays_blocked():
 
 
 @pytest.mark.gpu
+def test_cpp_host_device_group_constructor(tmp_path):
+    """Renderer(std::vector<int>{0, 0}): the C++ face of the device group (two logical shards on one GPU) gives the single-device
+    image up to the order of the final sum."""
+    w, h, spp, bounces = 96, 54, 8, 5
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    r1 = run_shim([FIXTURE, w, h, spp, bounces, one], timeout=300)
+    r2 = run_shim([FIXTURE, w, h, spp, bounces, two, 0, "0,0"], timeout=300)
+    assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr, r2.stderr)
+    a, b = np.fromfile(one + ".acc", np.float32), np.fromfile(two + ".acc", np.float32)
+    np.testing.assert_allclose(b, a, rtol=1e-6, atol=1e-7)
+    assert np.abs(np.fromfile(one + ".rgba", np.uint8).astype(int) - np.fromfile(two + ".rgba", np.uint8).astype(int)).max() <= 1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("buckets", [0, 3])
 def test_cpp_host_renders_the_fixture_like_the_python_host_and_the_oracle(tmp_path, buckets):
     """One render() per frame from C++ gives the accumulator, the RGBA8 readback and the presented device image that the Python host
