@@ -10,7 +10,10 @@
 // PARITY PINNING: the reference has no tests, golden vectors or fixtures and cannot be built or run
 // in this pipeline (Metal/macOS only).  What IS pinned: the integer sampler known-answers of SURVEY §8a
 // (tests/golden/sampler_kat.json), the LUT data files themselves (decoded by the reference's vendored tinyexr,
-// tools/make_lut_blob.py --check-tinyexr) and closed-form checks (fresnel(1,1.5)=0.04, white-furnace of E).
+// tools/make_lut_blob.py --check-tinyexr), closed-form checks (fresnel(1,1.5)=0.04, white-furnace of E) and — round 2 — the BSDF
+// pieces (GGX D / G / VNDF sampling, Fresnel, the dielectric lobes) against the reference's committed energy tables: namespace lutgen
+// below restates the reference's generator (ms_lut_gen.metal:337-743) on top of THIS file's BSDF functions and re-integrates all
+// eight tables (tests/test_lut_pin.py, tools/lut_pin.py: agreement to ~3e-4).
 // Ray/triangle intersection and texture filtering are Apple-closed in the reference and are DEFINED
 // here: => "parity unpinned" for hit selection, LUT interpolation rounding and the float radiance.
 //
