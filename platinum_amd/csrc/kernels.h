@@ -44,9 +44,9 @@ void launch_shade(hipStream_t s, uint32_t grid, const DeviceScene* S_device, Pat
                   ShadowQueue sq, vec4* Lbuf, Segments seg, uint32_t cur, BatchCounters* ctr, uint32_t bounce);
 void launch_trace_shadow(hipStream_t s, uint32_t grid, const DeviceScene& S, ShadowQueue sq, vec4* Lbuf, Segments seg,
                          BatchCounters* ctr, uint32_t bounce, uint32_t* spill, bool count);
-void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npixels, uint32_t nsamples, uint32_t n0,
+void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npixels, uint32_t width, uint32_t nsamples, uint32_t n0,
                        uint32_t nonfinite_policy, BatchCounters* ctr);
-void launch_accumulate_gmon(hipStream_t s, vec4* buckets, const vec4* Lbuf, uint32_t npixels, uint32_t nsamples, uint32_t n0,
+void launch_accumulate_gmon(hipStream_t s, vec4* buckets, const vec4* Lbuf, uint32_t npixels, uint32_t width, uint32_t nsamples, uint32_t n0,
                             uint32_t samples_per_bucket, uint32_t gmon_buckets, uint32_t bucket_base, uint32_t nonfinite_policy, BatchCounters* ctr);
 // out[p] = (first ? 0 : out[p]) + w * in[p]  — merging the accumulators of a device group's members (alpha is set to 1 by the last call)
 void launch_weighted_add(hipStream_t s, vec4* out, const vec4* in, float w, uint32_t npixels, bool first, bool last);

@@ -186,6 +186,25 @@ __global__ void __launch_bounds__(1024) k_chunk_tables(Segments seg, uint32_t cu
   }
 }
 
+// ---- the per-sample radiance buffer Lbuf -----------------------------------------------------------------------------
+// One vec4 per (pixel, sample in flight), laid out TILE-major: [8x8 tile][sample][lane = (y & 7) * 8 + (x & 7)].  The entries of one
+// tile under all samples are contiguous (64 KB at 64 samples in flight) and a segment's rays all belong to its tile(s): the shadow
+// kernel's read-modify-writes of a segment stay inside that window (a [sample][pixel] layout spread them over 64 planes 33 MB
+// apart: every access its own line).  `pid` in the path state IS this index.
+__device__ __forceinline__ uint32_t lbuf_index(uint32_t tile, uint32_t s, uint32_t nsamples, uint32_t lane) {
+  return (tile * nsamples + s) * 64u + lane;
+}
+__device__ __forceinline__ uint32_t lbuf_index_of_pixel(uint32_t p, uint32_t W, uint32_t s, uint32_t nsamples) {
+  const uint32_t y = p / W, x = p - y * W, tilesX = (W + 7u) / 8u;
+  return lbuf_index((y >> 3) * tilesX + (x >> 3), s, nsamples, (y & 7u) * 8u + (x & 7u));
+}
+// the pixel (row-major) of a pid of a ONE-sample batch (the debug entry points: pt_trace_primary, pt_debug_sample)
+__device__ __forceinline__ uint32_t pixel_of_pid_1spp(uint32_t pid, uint32_t W) {
+  const uint32_t lane = pid & 63u, tile = pid >> 6, tilesX = (W + 7u) / 8u;
+  const uint32_t ty = tile / tilesX, tx = tile - ty * tilesX;
+  return (ty * 8u + (lane >> 3)) * W + tx * 8u + (lane & 7u);
+}
+
 // ---- raygen ------------------------------------------------------------------------------------------------------
 // One 8x8 pixel tile of one sample per wave iteration (a coherent camera-ray bundle).  Lanes outside the image
 // (partial edge tiles) are squeezed out.  Segment s = T consecutive tiles under all samples of the batch
@@ -215,7 +234,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DeviceScene S, PathState st, 
       const unsigned long long m = __ballot(valid);
       if (valid) {
         const uint32_t j = seg_slot(seg.nseg, sg, n_out + wave_prefix(m));
-        const uint32_t pid = s * (S.width * S.height) + y * S.width + x;
+        const uint32_t pid = lbuf_index(tile, s, nsamples, lane);
         st.rayO[j] = vec4{rg.o.x, rg.o.y, rg.o.z, 0.0f};
         st.rayD[j] = vec4{rg.d.x, rg.d.y, rg.d.z, u2f(rg.dim & kMetaDimMask)};
         st.att[j] = vec4{1.0f, 1.0f, 1.0f, u2f(rg.offset)};
@@ -318,8 +337,8 @@ k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments se
     const RayHit& h = ts.best;
     hit[ray] = vec4{h.t, h.u, h.v, u2f(h.tri == kInvalidRef ? kInvalidRef : (h.tri | ((h.gid & 3u) << 28)))};
     if (hitlog) {
-      const uint32_t pid = st.pid[ray];
-      int32_t* hl = &hitlog[((size_t)bounce * log_stride + pid) * 2];
+      const uint32_t pixel = pixel_of_pid_1spp(st.pid[ray], S.width);  // (the hit log is only kept for one-sample batches)
+      int32_t* hl = &hitlog[((size_t)bounce * log_stride + pixel) * 2];
       hl[0] = h.tri != kInvalidRef ? (int32_t)S.tris[h.tri].inst : -1;
       hl[1] = h.tri != kInvalidRef ? (int32_t)S.tris[h.tri].prim : -1;
     }
@@ -643,13 +662,14 @@ k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments 
 
 // ---- accumulate (kernel.metal:672-684): running mean, one sample at a time, in sample order --------------------------
 __global__ void __launch_bounds__(kBlock) k_accumulate(vec4* __restrict__ acc, const vec4* __restrict__ Lbuf,
-                                                        uint32_t npixels, uint32_t nsamples, uint32_t n0,
+                                                        uint32_t npixels, uint32_t width, uint32_t nsamples, uint32_t n0,
                                                         uint32_t nonfinite_policy, BatchCounters* __restrict__ ctr) {
   const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= npixels) return;
   vec4 a = acc[p];
+  const uint32_t l0 = lbuf_index_of_pixel(p, width, 0, nsamples);
   for (uint32_t s = 0; s < nsamples; s++) {
-    const vec4 L4 = Lbuf[(size_t)s * npixels + p];
+    const vec4 L4 = Lbuf[l0 + s * 64u];
     vec3 L = v3(L4.x, L4.y, L4.z);
     if (!(fabsf(L.x) <= 3.0e38f && fabsf(L.y) <= 3.0e38f && fabsf(L.z) <= 3.0e38f)) {  // NaN or inf
       atomicAdd(&ctr->nonfinite, 1u);
@@ -670,13 +690,14 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(vec4* __restrict__ acc, c
 // f / ceil(spp / buckets) (renderer_pt.cpp:124-139) with the running-mean weight n = f / gmonBuckets
 // (kernel.metal:675-681 — note: NOT the sample's index inside its bucket; reproduced as is).
 __global__ void __launch_bounds__(kBlock) k_accumulate_gmon(vec4* __restrict__ buckets, const vec4* __restrict__ Lbuf,
-                                                             uint32_t npixels, uint32_t nsamples, uint32_t n0,
+                                                             uint32_t npixels, uint32_t width, uint32_t nsamples, uint32_t n0,
                                                              uint32_t samples_per_bucket, uint32_t gmon_buckets, uint32_t bucket_base,
                                                              uint32_t nonfinite_policy, BatchCounters* __restrict__ ctr) {
   const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= npixels) return;
+  const uint32_t l0 = lbuf_index_of_pixel(p, width, 0, nsamples);
   for (uint32_t s = 0; s < nsamples; s++) {
-    const vec4 L4 = Lbuf[(size_t)s * npixels + p];
+    const vec4 L4 = Lbuf[l0 + s * 64u];
     vec3 L = v3(L4.x, L4.y, L4.z);
     if (!(fabsf(L.x) <= 3.0e38f && fabsf(L.y) <= 3.0e38f && fabsf(L.z) <= 3.0e38f)) {
       atomicAdd(&ctr->nonfinite, 1u);
@@ -811,7 +832,7 @@ __global__ void __launch_bounds__(kBlock) k_hit_records(DeviceScene S, PathState
       } else {
         r.t = 0.0f; r.u = 0.0f; r.v = 0.0f; r.instance = -1; r.primitive = -1;
       }
-      out[st.pid[i]] = r;
+      out[pixel_of_pid_1spp(st.pid[i], S.width)] = r;
     }
   }
 }
@@ -859,14 +880,14 @@ void launch_trace_shadow(hipStream_t s, uint32_t grid, const DeviceScene& S, Sha
   if (count) hipLaunchKernelGGL((k_trace_shadow<true, false>), dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, seg, ctr, bounce, spill);
   else hipLaunchKernelGGL((k_trace_shadow<false, false>), dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, seg, ctr, bounce, spill);
 }
-void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npixels, uint32_t nsamples, uint32_t n0,
+void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npixels, uint32_t width, uint32_t nsamples, uint32_t n0,
                        uint32_t nonfinite_policy, BatchCounters* ctr) {
-  hipLaunchKernelGGL(k_accumulate, dim3((npixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, acc, Lbuf, npixels, nsamples, n0,
+  hipLaunchKernelGGL(k_accumulate, dim3((npixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, acc, Lbuf, npixels, width, nsamples, n0,
                      nonfinite_policy, ctr);
 }
-void launch_accumulate_gmon(hipStream_t s, vec4* buckets, const vec4* Lbuf, uint32_t npixels, uint32_t nsamples, uint32_t n0,
+void launch_accumulate_gmon(hipStream_t s, vec4* buckets, const vec4* Lbuf, uint32_t npixels, uint32_t width, uint32_t nsamples, uint32_t n0,
                             uint32_t samples_per_bucket, uint32_t gmon_buckets, uint32_t bucket_base, uint32_t nonfinite_policy, BatchCounters* ctr) {
-  hipLaunchKernelGGL(k_accumulate_gmon, dim3((npixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, buckets, Lbuf, npixels, nsamples, n0,
+  hipLaunchKernelGGL(k_accumulate_gmon, dim3((npixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, buckets, Lbuf, npixels, width, nsamples, n0,
                      samples_per_bucket, gmon_buckets, bucket_base, nonfinite_policy, ctr);
 }
 void launch_weighted_add(hipStream_t s, vec4* out, const vec4* in, float w, uint32_t npixels, bool first, bool last) {

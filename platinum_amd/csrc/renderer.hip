@@ -91,12 +91,12 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
       const uint32_t total_spp = r->gmon_total_spp ? r->gmon_total_spp : r->params.spp;
       const uint32_t spb = (total_spp + buckets - 1) / buckets;  // renderer_pt.cpp:124-125
       const uint32_t f0 = n0 + r->gmon_sample_base;              // (a member of a device group: index within the whole render)
-      launch_accumulate_gmon(s, r->gmon_buckets_d.p, r->Lbuf.p, npix, ns, f0, spb, buckets, r->gmon_bucket_base, r->params.nonfinite_policy, ctr);
+      launch_accumulate_gmon(s, r->gmon_buckets_d.p, r->Lbuf.p, npix, S.width, ns, f0, spb, buckets, r->gmon_bucket_base, r->params.nonfinite_policy, ctr);
       // the reference resolves after every frame with fullBuckets = gmonIdx + 1 (renderer_pt.cpp:164-179); only the last
       // resolve of a batch is observable
       launch_gmon(s, r->acc, r->gmon_buckets_d.p, npix, (f0 + ns - 1) / spb + 1 - r->gmon_bucket_base, r->gmon_cap);
     } else {
-      launch_accumulate(s, r->acc, r->Lbuf.p, npix, ns, n0, r->params.nonfinite_policy, ctr);
+      launch_accumulate(s, r->acc, r->Lbuf.p, npix, S.width, ns, n0, r->params.nonfinite_policy, ctr);
     }
   }
   // BATCH_DEBUG still folds (to clear the per-wave statistics) but into a scratch Totals slot
@@ -412,7 +412,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   }
   PT_HIP(r->hit.alloc(r->capacity));
   PT_HIP(r->sq_o.alloc(r->capacity)); PT_HIP(r->sq_d.alloc(r->capacity)); PT_HIP(r->sq_c.alloc(r->capacity));
-  PT_HIP(r->Lbuf.alloc((size_t)npix * sif));
+  PT_HIP(r->Lbuf.alloc((size_t)((p->width + 7) / 8) * ((p->height + 7) / 8) * 64 * sif));  // tile-major, whole tiles (kernels.hip lbuf_index)
   for (int k = 0; k < 2; k++) PT_HIP(r->seg_active[k].alloc(r->nseg));
   PT_HIP(r->seg_shadow.alloc(r->nseg));
   PT_HIP(r->wave_stats.alloc(r->nstats));
@@ -662,7 +662,17 @@ int dev_debug_sample(pt_renderer* r, uint32_t sample_idx, float* radiance_out, i
   if (rc != PT_OK) return rc;
   PT_HIP(hipStreamSynchronize(r->stream));
   r->drop_timed();
-  if (radiance_out) PT_HIP(hipMemcpy(radiance_out, r->Lbuf.p, sizeof(vec4) * npix, hipMemcpyDeviceToHost));
+  if (radiance_out) {  // Lbuf of a one-sample batch is [tile][lane]: bring it back and put it in image order
+    const uint32_t W = r->S.width, H = r->S.height, tilesX = (W + 7) / 8, tilesY = (H + 7) / 8;
+    std::vector<vec4> tiled((size_t)tilesX * tilesY * 64);
+    PT_HIP(hipMemcpy(tiled.data(), r->Lbuf.p, sizeof(vec4) * tiled.size(), hipMemcpyDeviceToHost));
+    for (uint32_t y = 0; y < H; y++)
+      for (uint32_t x = 0; x < W; x++) {
+        const vec4& v = tiled[((size_t)(y >> 3) * tilesX + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7)];
+        float* o = radiance_out + ((size_t)y * W + x) * 4;
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+      }
+  }
   if (hits_out) PT_HIP(hipMemcpy(hits_out, log.p, sizeof(int32_t) * log.n, hipMemcpyDeviceToHost));
   return PT_OK;
 }
