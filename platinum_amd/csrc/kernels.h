@@ -12,7 +12,7 @@ constexpr int kBlock = 256;  // 4 waves; traversal kernels keep a 16 KiB LDS sta
 struct WaveStats { unsigned long long closest, shadow, shaded, paths; };  // per physical wave, owner-updated, reduced by k_fold_counters
 
 // Queue segments (kernels.hip): segment s = the queue share of tiles [s * tiles_per_seg, (s + 1) * tiles_per_seg) under all
-// samples of a batch; it owns `seg_cap` slots of every queue array (chunk-interleaved) and one count per queue.
+// samples of a batch; it owns `seg_cap` slots of every queue array (interleaved in groups of 16 chunks) and one count per queue.
 struct Segments {
   uint32_t* active[2];  // [state buffer][segment] live paths in the segment
   uint32_t* shadow;     // [segment] shadow rays in the segment
@@ -33,6 +33,7 @@ void launch_raygen(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState
 // `bounce_closest`) and, if do_shadow, of the shadow queue consumed at `bounce_shadow`.
 void launch_chunk_tables(hipStream_t s, Segments seg, uint32_t cur, BatchCounters* ctr, uint32_t bounce_closest,
                          uint32_t bounce_shadow, bool do_shadow);
+uint32_t seg_group_chunks();
 uint32_t trace_block_threads(bool two_level);
 uint32_t trace_blocks_per_cu_two_level();  // 256 (7 blocks per CU) for one BVH, 1024 (one block per CU) for the two-level structure
 void launch_trace_closest(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, vec4* hit, Segments seg, uint32_t cur,

@@ -6,7 +6,7 @@
 //
 // Queues are SEGMENTS.  A segment is the queue share of a few 8x8 pixel tiles (Segments::tiles_per_seg, 1 unless the image
 // has more than 32768 tiles) under all samples of the batch: segment s owns the slots {seg_slot(s, r) : r < seg_cap} of
-// every queue array (chunk-interleaved, see seg_slot) and one count per queue.  A segment is always processed by ONE wave
+// every queue array (interleaved in groups of 16 chunks, see seg_slot) and one count per queue.  A segment is always processed by ONE wave
 // at a time, front to back: k_raygen fills it, k_shade shades it and compacts the survivors (ballot + mbcnt prefix) into
 // the same segment of the other state buffer and its NEE rays into the same segment of the shadow queue.  Survivors <=
 // inputs, so a segment never overflows and NO atomic sits on the producer side.  (Round-1 measurement: with one global
@@ -57,10 +57,18 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // physical wave id / count of the launch (blockDim.x is a multiple of 64)
 __device__ __forceinline__ uint32_t wave_index() { return blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); }
 __device__ __forceinline__ uint32_t wave_count() { return gridDim.x * (blockDim.x >> 6); }
-// Slot of entry r of segment s.  Segments are CHUNK-INTERLEAVED: the k-th 64-entry chunk of every segment is stored
-// back to back ((k * nseg + s) * 64): chunk k of neighbouring tiles is contiguous, and no segment's base address
-// aliases another's in the memory channels (a segment-major layout cost the closest-hit kernel 1.4x).
-__device__ __forceinline__ uint32_t seg_slot(uint32_t nseg, uint32_t s, uint32_t r) { return ((r >> 6) * nseg + s) * 64u + (r & 63u); }
+// Slot of entry r of segment s.  Segments are interleaved in GROUPS of PT_SEG_GROUP 64-entry chunks: chunks 16g .. 16g + 15 of a
+// segment are contiguous (16 KB per array), group g of neighbouring segments follows — a segment's entries are a few long runs
+// (the class-binned passes of k_shade gather from them; +1 % over single-chunk interleaving), while concurrently processed
+// segments still start in different memory channels (a plain segment-major layout cost the closest-hit kernel 1.4x in round 1).
+#ifndef PT_SEG_GROUP
+#define PT_SEG_GROUP 16
+#endif
+__device__ __forceinline__ uint32_t seg_slot(uint32_t nseg, uint32_t s, uint32_t r) {
+  const uint32_t k = r >> 6;
+  return (((k / PT_SEG_GROUP) * nseg + s) * PT_SEG_GROUP + (k % PT_SEG_GROUP)) * 64u + (r & 63u);
+}
+uint32_t seg_group_chunks() { return PT_SEG_GROUP; }
 
 // ---- chunk claims for the trace kernels ------------------------------------------------------------------------------
 // 64-ray chunks claimed per cursor atomic.  ONE L2 address sustains ~88 returning atomics per microsecond

@@ -405,7 +405,10 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
     r->seg_cap = r->tiles_per_seg * sif * 64;
     r->nstats = std::max(r->grid * (kBlock / 64), r->shade_grid * (shade_block_threads() / 64));
   }
-  r->capacity = (size_t)r->nseg * r->seg_cap;  // >= npix * sif
+  {
+    const uint32_t G = seg_group_chunks(), K = r->seg_cap / 64;
+    r->capacity = (size_t)r->nseg * ((K + G - 1) / G * G) * 64;  // >= npix * sif
+  }
   for (int k = 0; k < 2; k++) {
     PT_HIP(r->st_rayO[k].alloc(r->capacity)); PT_HIP(r->st_rayD[k].alloc(r->capacity));
     PT_HIP(r->st_att[k].alloc(r->capacity)); PT_HIP(r->st_pid[k].alloc(r->capacity));
