@@ -22,6 +22,7 @@ struct Segments {
   uint32_t seg_cap;     // slots per segment (a multiple of 64) = tiles_per_seg * samples_in_flight * 64
   uint32_t nseg;        // segments (<= 32768: k_chunk_tables packs the id into 16 bits and scans <= 1024 per block)
   uint32_t tiles_per_seg;
+  uint32_t nsamples;      // samples of the current batch (the per-sample radiance buffer holds nsamples * 64 entries per tile)
   uint32_t bands;         // consecutive segments cycle over this many horizontal bands of the image (nseg % bands == 0)
   uint32_t nstats;      // WaveStats slots (>= waves of the largest producer grid)
   uint32_t refill_threshold; // trace kernels: refill a wave's idle lanes when fewer than this many still hold a ray (0 = only when all idle)

@@ -206,6 +206,16 @@ __device__ __forceinline__ uint32_t lbuf_index_of_pixel(uint32_t p, uint32_t W, 
   const uint32_t y = p / W, x = p - y * W, tilesX = (W + 7u) / 8u;
   return lbuf_index((y >> 3) * tilesX + (x >> 3), s, nsamples, (y & 7u) * 8u + (x & 7u));
 }
+// A segment's window of Lbuf starts at its first tile; a path's entry is that base + the relative index it carries in rayD.w.
+__device__ __forceinline__ uint32_t segment_first_tile(const Segments& seg, uint32_t sg) {
+  // consecutive segments cycle over `bands` horizontal bands of the image (the chunk tables list the segments in order, so the
+  // rays in flight in a trace kernel come from `bands` neighbourhoods instead of one)
+  const uint32_t per_band = seg.nseg / seg.bands;  // nseg is a multiple of bands
+  return ((sg % seg.bands) * per_band + sg / seg.bands) * seg.tiles_per_seg;
+}
+__device__ __forceinline__ uint32_t segment_lbuf_base(const Segments& seg, uint32_t sg) { return segment_first_tile(seg, sg) * seg.nsamples * 64u; }
+// the segment a queue slot belongs to (inverse of seg_slot)
+__device__ __forceinline__ uint32_t slot_segment(uint32_t nseg, uint32_t slot) { return ((slot >> 6) / PT_SEG_GROUP) % nseg; }
 // the pixel (row-major) of a pid of a ONE-sample batch (the debug entry points: pt_trace_primary, pt_debug_sample)
 __device__ __forceinline__ uint32_t pixel_of_pid_1spp(uint32_t pid, uint32_t W) {
   const uint32_t lane = pid & 63u, tile = pid >> 6, tilesX = (W + 7u) / 8u;
@@ -225,10 +235,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DeviceScene S, PathState st, 
   uint32_t started = 0;
   for (uint32_t sg = wave_index(); sg < seg.nseg; sg += wave_count()) {
     uint32_t n_out = 0;
-    // segment -> tiles: consecutive segments cycle over `bands` horizontal bands of the image (the chunk tables list the
-    // segments in order, so the rays in flight in a trace kernel come from `bands` neighbourhoods instead of one)
-    const uint32_t per_band = seg.nseg / seg.bands;  // nseg is a multiple of bands
-    const uint32_t first_tile = ((sg % seg.bands) * per_band + sg / seg.bands) * seg.tiles_per_seg;
+    const uint32_t first_tile = segment_first_tile(seg, sg);
     for (uint32_t k = 0; k < seg.tiles_per_seg * nsamples; k++) {
       const uint32_t tile = first_tile + k / nsamples;
       const uint32_t s = k % nsamples;
@@ -242,11 +249,10 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DeviceScene S, PathState st, 
       const unsigned long long m = __ballot(valid);
       if (valid) {
         const uint32_t j = seg_slot(seg.nseg, sg, n_out + wave_prefix(m));
-        const uint32_t pid = lbuf_index(tile, s, nsamples, lane);
+        const uint32_t pid = lbuf_index(tile, s, nsamples, lane);  // = segment_lbuf_base(seg, sg) + k * 64 + lane
         st.rayO[j] = vec4{rg.o.x, rg.o.y, rg.o.z, 0.0f};
-        st.rayD[j] = vec4{rg.d.x, rg.d.y, rg.d.z, u2f(rg.dim & kMetaDimMask)};
+        st.rayD[j] = vec4{rg.d.x, rg.d.y, rg.d.z, u2f((rg.dim & kMetaDimMask) | ((k * 64u + lane) << kMetaPidShift))};
         st.att[j] = vec4{1.0f, 1.0f, 1.0f, u2f(rg.offset)};
-        st.pid[j] = pid;
         Lbuf[pid] = vec4{0.0f, 0.0f, 0.0f, 1.0f};
       }
       n_out += (uint32_t)__popcll(m);
@@ -345,7 +351,8 @@ k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments se
     const RayHit& h = ts.best;
     hit[ray] = vec4{h.t, h.u, h.v, u2f(h.tri == kInvalidRef ? kInvalidRef : (h.tri | ((h.gid & 3u) << 28)))};
     if (hitlog) {
-      const uint32_t pixel = pixel_of_pid_1spp(st.pid[ray], S.width);  // (the hit log is only kept for one-sample batches)
+      // (the hit log is only kept for one-sample batches)
+      const uint32_t pixel = pixel_of_pid_1spp(segment_lbuf_base(seg, slot_segment(seg.nseg, ray)) + (f2u(st.rayD[ray].w) >> kMetaPidShift), S.width);
       int32_t* hl = &hitlog[((size_t)bounce * log_stride + pixel) * 2];
       hl[0] = h.tri != kInvalidRef ? (int32_t)S.tris[h.tri].inst : -1;
       hl[1] = h.tri != kInvalidRef ? (int32_t)S.tris[h.tri].prim : -1;
@@ -453,6 +460,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
   uint16_t* bin = &lds_bins[threadIdx.x >> 6][0][0];  // this wave's bins: [class][kBinCap] slot numbers within the segment
   uint32_t* bin_tri = &lds_bin_tri[threadIdx.x >> 6][0][0];
   while (sg < seg.nseg) {
+    const uint32_t lbuf_base = segment_lbuf_base(seg, sg);  // this segment's window of the per-sample radiance buffer
     const uint32_t n = __builtin_amdgcn_readfirstlane(seg.active[cur][sg]);  // (a scalar for the compiler too: the scan loop and the bin counters stay in SGPRs)
     uint32_t n_out = 0, n_shadow = 0;
     // ---- hits are shaded one MATERIAL CLASS per wave pass.  The segment is scanned 64 slots at a time; every slot number goes
@@ -517,7 +525,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
         const vec4 d4 = sin.rayD[i];
         const vec4 a4 = sin.att[i];
         const vec3 Le = stage_miss(S, v3(d4.x, d4.y, d4.z), v3(a4.x, a4.y, a4.z), bounce, o4.w, (f2u(d4.w) & kMetaSpecular) != 0);
-        const uint32_t mpid = sin.pid[i];
+        const uint32_t mpid = lbuf_base + (f2u(d4.w) >> kMetaPidShift);
         vec4 L = Lbuf[mpid];
         L.x += Le.x; L.y += Le.y; L.z += Le.z;
         Lbuf[mpid] = L;
@@ -528,8 +536,8 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
         const vec4 o4 = ld_stream(&sin.rayO[i]);
         const vec4 d4 = ld_stream(&sin.rayD[i]);
         const vec4 a4 = ld_stream(&sin.att[i]);
-        const uint32_t pid = ld_stream(&sin.pid[i]);
         const uint32_t meta = f2u(d4.w);
+        const uint32_t pid = lbuf_base + (meta >> kMetaPidShift);
         ShadeIn in;
         in.o = v3(o4.x, o4.y, o4.z);
         in.d = v3(d4.x, d4.y, d4.z);
@@ -571,9 +579,8 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
         if (bo.alive) {
           const uint32_t j = seg_slot(seg.nseg, sg, n_out + wave_prefix(m));
           st_stream(&sout.rayO[j], vec4{g.hitPos.x, g.hitPos.y, g.hitPos.z, bo.next_pdf});
-          st_stream(&sout.rayD[j], vec4{bo.next_d.x, bo.next_d.y, bo.next_d.z, u2f((bo.dim & kMetaDimMask) | (bo.next_specular ? kMetaSpecular : 0u))});
+          st_stream(&sout.rayD[j], vec4{bo.next_d.x, bo.next_d.y, bo.next_d.z, u2f((bo.dim & kMetaDimMask) | (bo.next_specular ? kMetaSpecular : 0u) | (meta & ~(kMetaDimMask | kMetaSpecular)))});
           st_stream(&sout.att[j], vec4{bo.next_att.x, bo.next_att.y, bo.next_att.z, u2f(in.offset)});
-          st_stream(&sout.pid[j], pid);
         }
         c_alive = (uint32_t)__popcll(m);
       }
@@ -840,7 +847,7 @@ __global__ void __launch_bounds__(kBlock) k_hit_records(DeviceScene S, PathState
       } else {
         r.t = 0.0f; r.u = 0.0f; r.v = 0.0f; r.instance = -1; r.primitive = -1;
       }
-      out[pixel_of_pid_1spp(st.pid[i], S.width)] = r;
+      out[pixel_of_pid_1spp(segment_lbuf_base(seg, sg) + (f2u(st.rayD[i].w) >> kMetaPidShift), S.width)] = r;
     }
   }
 }

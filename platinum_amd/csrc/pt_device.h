@@ -201,16 +201,17 @@ struct DeviceScene {
 
 // ---- wavefront state (SoA, one element per path slot; ping-pong between bounces) ---------------------------------
 // rayO.w  = pdf of the BSDF sample that generated this ray (lastSample.pdf, kernel.metal:574)
-// rayD.w  = bits: [9:0] next Halton dimension, [10] lastSample was specular (kernel.metal:561)
+// rayD.w  = bits: [9:0] next Halton dimension, [10] lastSample was specular (kernel.metal:561), [31:11] the path's entry of the
+//           per-sample radiance buffer, relative to the window of its segment (kernels.hip lbuf_index; a path never leaves its segment)
 // att.w   = bits: Halton offset of this (pixel, sample) (samplers.metal:154-156)
 struct PathState {
   vec4* rayO;
   vec4* rayD;
   vec4* att;
-  uint32_t* pid;   // sample_slot * W*H + pixel : index into the per-sample radiance buffer
 };
 constexpr uint32_t kMetaDimMask = 0x3ffu;
 constexpr uint32_t kMetaSpecular = 1u << 10;
+constexpr uint32_t kMetaPidShift = 11;  // bits 11..31: the path's index into Lbuf RELATIVE to its segment's window (< 2^21)
 
 struct ShadowQueue {
   vec4* o;        // origin.xyz, tmax

@@ -58,7 +58,8 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
   BatchCounters* ctr = r->ctr.p;
   PT_HIP(hipMemsetAsync(ctr, 0, sizeof(BatchCounters), s));
   const bool count = mode == BATCH_MEASURE;
-  const Segments seg = r->segments();
+  Segments seg = r->segments();
+  seg.nsamples = ns;
   {
     ScopedTimer t(r, K_RAYGEN);
     launch_raygen(s, r->grid, S, r->path_state(0), r->Lbuf.p, seg, ctr, first, ns);
@@ -401,7 +402,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
     if (r->tiles_per_seg_override) r->tiles_per_seg = std::max(r->tiles_per_seg, r->tiles_per_seg_override);
     r->nseg = (uint32_t)((tiles + r->tiles_per_seg - 1) / r->tiles_per_seg);
     r->nseg = (r->nseg + r->seg_bands - 1) / r->seg_bands * r->seg_bands;  // (segments past the last tile stay empty)
-    if ((uint64_t)r->tiles_per_seg * sif >= 65536) return fail(PT_ERR_INVALID_ARGUMENT, "image x samples_in_flight too large for the chunk tables");
+    if ((uint64_t)r->tiles_per_seg * sif >= 32768) return fail(PT_ERR_INVALID_ARGUMENT, "image x samples_in_flight too large for the chunk tables");
     r->seg_cap = r->tiles_per_seg * sif * 64;
     r->nstats = std::max(r->grid * (kBlock / 64), r->shade_grid * (shade_block_threads() / 64));
   }
@@ -411,7 +412,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   }
   for (int k = 0; k < 2; k++) {
     PT_HIP(r->st_rayO[k].alloc(r->capacity)); PT_HIP(r->st_rayD[k].alloc(r->capacity));
-    PT_HIP(r->st_att[k].alloc(r->capacity)); PT_HIP(r->st_pid[k].alloc(r->capacity));
+    PT_HIP(r->st_att[k].alloc(r->capacity));
   }
   PT_HIP(r->hit.alloc(r->capacity));
   PT_HIP(r->sq_o.alloc(r->capacity)); PT_HIP(r->sq_d.alloc(r->capacity)); PT_HIP(r->sq_c.alloc(r->capacity));
@@ -640,11 +641,13 @@ int dev_trace_primary(pt_renderer* r, uint32_t sample_idx, pt_hit_record* out) {
   PT_HIP(rec.alloc(npix));
   hipStream_t s = r->stream;
   PT_HIP(hipMemsetAsync(r->ctr.p, 0, sizeof(BatchCounters), s));
-  launch_raygen(s, r->grid, r->S, r->path_state(0), r->Lbuf.p, r->segments(), r->ctr.p, sample_idx, 1);
-  launch_chunk_tables(s, r->segments(), 0, r->ctr.p, 0, 0, false);
-  launch_trace_closest(s, r->trace_grid, r->S, r->path_state(0), r->hit.p, r->segments(), 0, r->ctr.p, 0, r->spill.p, nullptr, npix, false);
-  launch_hit_records(s, r->grid, r->S, r->path_state(0), r->hit.p, r->segments(), rec.p);
-  launch_fold_counters(s, r->ctr.p, r->totals.p + 1, r->segments(), false);  // clears the per-wave statistics (scratch slot)
+  Segments seg = r->segments();
+  seg.nsamples = 1;
+  launch_raygen(s, r->grid, r->S, r->path_state(0), r->Lbuf.p, seg, r->ctr.p, sample_idx, 1);
+  launch_chunk_tables(s, seg, 0, r->ctr.p, 0, 0, false);
+  launch_trace_closest(s, r->trace_grid, r->S, r->path_state(0), r->hit.p, seg, 0, r->ctr.p, 0, r->spill.p, nullptr, npix, false);
+  launch_hit_records(s, r->grid, r->S, r->path_state(0), r->hit.p, seg, rec.p);
+  launch_fold_counters(s, r->ctr.p, r->totals.p + 1, seg, false);  // clears the per-wave statistics (scratch slot)
   PT_HIP(hipGetLastError());
   PT_HIP(hipStreamSynchronize(s));
   PT_HIP(hipMemcpy(out, rec.p, sizeof(pt_hit_record) * npix, hipMemcpyDeviceToHost));

@@ -102,7 +102,7 @@ struct pt_renderer {
   uint32_t samples_in_flight = 0;
   size_t capacity = 0;  // path slots
   DevBuf<vec4> st_rayO[2], st_rayD[2], st_att[2], hit, sq_o, sq_d, sq_c, Lbuf, acc_own;
-  DevBuf<uint32_t> st_pid[2], spill, seg_active[2], seg_shadow;
+  DevBuf<uint32_t> spill, seg_active[2], seg_shadow;
   DevBuf<WaveStats> wave_stats;
   DevBuf<uint32_t> chunk_table[2];
   DevBuf<vec4> gmon_buckets_d;  // [bucket][pixel] with PT_FLAG_GMON (renderer_pt.cpp:824-830)
@@ -136,9 +136,9 @@ struct pt_renderer {
   uint64_t launches[K_CLASSES] = {0, 0, 0, 0, 0};
   double upload_ms = 0, bvh_ms = 0;
 
-  PathState path_state(int k) { return PathState{st_rayO[k].p, st_rayD[k].p, st_att[k].p, st_pid[k].p}; }
+  PathState path_state(int k) { return PathState{st_rayO[k].p, st_rayD[k].p, st_att[k].p}; }
   ShadowQueue shadow_queue() { return ShadowQueue{sq_o.p, sq_d.p, sq_c.p}; }
-  Segments segments() { return Segments{{seg_active[0].p, seg_active[1].p}, seg_shadow.p, wave_stats.p, chunk_table[0].p, chunk_table[1].p, seg_cap, nseg, tiles_per_seg, seg_bands, nstats, refill_threshold}; }
+  Segments segments() { return Segments{{seg_active[0].p, seg_active[1].p}, seg_shadow.p, wave_stats.p, chunk_table[0].p, chunk_table[1].p, seg_cap, nseg, tiles_per_seg, /*nsamples: set per batch*/ 0u, seg_bands, nstats, refill_threshold}; }
 
   void free_scene() {
     positions.release(); vdata.release(); indices.release(); slots.release(); meshes.release(); instances.release();
@@ -148,7 +148,7 @@ struct pt_renderer {
     if (bvh.mesh_trav) (void)hipFree(bvh.mesh_trav);
     inst_trav.release();
     bvh = LbvhResult{};
-    for (int k = 0; k < 2; k++) { st_rayO[k].release(); st_rayD[k].release(); st_att[k].release(); st_pid[k].release(); }
+    for (int k = 0; k < 2; k++) { st_rayO[k].release(); st_rayD[k].release(); st_att[k].release(); }
     seg_active[0].release(); seg_active[1].release(); seg_shadow.release(); wave_stats.release(); chunk_table[0].release(); chunk_table[1].release(); gmon_buckets_d.release(); render_target.release();
     hit.release(); sq_o.release(); sq_d.release(); sq_c.release(); Lbuf.release(); acc_own.release(); spill.release();
     acc = nullptr;
