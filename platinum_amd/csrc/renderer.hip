@@ -389,6 +389,11 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
     sif = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (free_b / 4) / (npix * 200ull)));
   }
   sif = std::min<uint32_t>(std::min<uint32_t>(sif, p->spp), 256);
+  {  // the queue slots and the per-sample radiance buffer are indexed with 32 bits (kernels.hip seg_slot, lbuf_index)
+    const uint64_t tiles = (uint64_t)((p->width + 7) / 8) * ((p->height + 7) / 8);
+    while (sif > 1 && tiles * 64 * sif >= (1ull << 31)) sif /= 2;
+    if (tiles * 64 * sif >= (1ull << 31)) return fail(PT_ERR_UNSUPPORTED, "pt_start_render: the image is too large for the 32-bit queue indices");
+  }
   r->samples_in_flight = sif;
   // Queue segments (kernels.hip): one per 8x8 tile (a few tiles each once the image has more than 32768 of them), each with
   // room for its tiles under all samples in flight.  The producers (raygen, shade) are persistent grids whose waves take
