@@ -22,10 +22,15 @@ steps with HIP events around every launch (on the renderer's stream).  Rank 0 pr
   roofline          the kernel with the largest device time, against every ceiling that could bind it
   roofline_kernels  the same block for each hot kernel (k_shade, k_trace_closest, k_trace_shadow)
   cpu_baseline      (N = 1) the CPU oracle on the host cores, bounded sample of the same workload
-Ceilings (MI355X_MICROARCH.md): HBM 8.0 TB/s; L2 34.5 TB/s aggregate; VALU issue 256 CU x 4 SIMD x 32 lanes x 2.4 GHz =
-78.6 T lane-ops/s; and, measured here (tools/calib_gather.hip), the rate at which the L2s serve random 64-byte requests: 80.9 G/s.  Algorithmic bytes follow SURVEY §8(d); counter-based bytes and VALU instruction counts per work item
-come from the committed rocprofv3 --pmc passes of this same command (profiles/r02_pmc_<workload>.json, tools/profile_round.sh),
-labelled with their source — they are not measured by this run.
+`roofline` is the contract's block for the dominant kernel: bound "hbm", achieved = HBM bytes the rocprofv3 counters saw per
+launch (FETCH_SIZE + WRITE_SIZE, corrected as MI355X_MICROARCH.md §HBM prescribes; committed per-item figures of
+profiles/<round>_pmc_<workload>.json x this run's items per launch) / this run's average launch time (HIP events), peak 8 TB/s,
+frac = achieved / peak, traffic = those bytes per launch.  SURVEY §8(d)'s ALGORITHMIC bytes are served mostly by L1 / L2 /
+Infinity Cache (they exceed the HBM peak), so they appear only as `algorithmic_GBs` / `algorithmic_over_counter`, never as a met
+target.  What actually binds each kernel is reported under `secondary`: VALU issue (256 CU x 4 SIMD x 32 lanes x 2.4 GHz =
+78.6 T lane-ops/s), the vector L1's tag-lookup rate (one per clock per CU: profiles/r03_calib_gather.md) and the rate at which
+the L2s serve random requests.  Counter figures come from the committed --pmc passes of this same command
+(tools/profile_round.sh), labelled with their source and the library they were taken on — they are not measured by this run.
 """
 import argparse
 import json
@@ -40,7 +45,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 L2_PEAK_GBS = 34500.0       # aggregate over the 8 XCD L2s
 VALU_PEAK_TLOPS = 78.6432   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz, in 1e12 lane-ops/s
-L2_REQ_PEAK_G = 80.9        # random 64-byte read requests the L2s serve per second, all hits (measured: profiles/r02_calib_gather.md)
+L2_REQ_PEAK_G = 80.9        # random 64-byte read requests served per second to lane-private gathers (profiles/r02_calib_gather.md; r03: see r03_calib_gather.md)
+L1_TAG_PEAK_G = 256 * 2.1   # vector-L1 tag lookups per second: one per clock per CU at the ~2.1 GHz the trace kernels hold (profiles/r03_calib_gather.md)
 HBM_TARGET_FRAC = 0.40      # north_star: ">= 40 % of HBM peak on the traversal kernel"
 
 WORKLOADS = {
@@ -84,6 +90,10 @@ def parse_args(argv=None):
                     help="under rocprofv3 --pmc: only full-size batches (no warm-up, no instrumented sample, no CPU leg, no event timing)")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the second (event-timed) pass")
     ap.add_argument("--c5-in-memory", action="store_true", help="c5: the procedural snapshot directly instead of the .glb + .exr ingestion path")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: a FIXED render of --spp samples per pixel split over the N GPUs (BASELINE.json configs[3], C4: "
+                         "`--gpus 8 --strong --spp 1024` = 8 x 128, one reduce); --steps is derived = ceil(spp / N / spp-per-step); reports time to image")
+    ap.add_argument("--spp", type=int, default=0, help="--strong: total samples per pixel of the render (default: the workload's full spp, 1024 for c3 = C4)")
     return ap.parse_args(argv)
 
 
@@ -113,9 +123,11 @@ def self_launch(args):
 
 def load_pmc_profile(workload):
     """Per-work-item counter figures of the committed rocprofv3 --pmc passes (tools/profile_round.sh + tools/summarize_prof.py)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % workload)
-    if not os.path.exists(path):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_%s.json" % workload)))
+    if not cands:
         return None, None
+    path = cands[-1]  # the newest round's
     try:
         return json.load(open(path)), os.path.relpath(path, ROOT)
     except Exception:
@@ -132,51 +144,52 @@ def library_sha16():
 
 
 def kernel_block(name, items, item_name, ms, launches, alg_bytes_per_item, pmc, pmc_src, lib_sha, extra=None):
-    """All ceilings for one kernel; `bound` = the ceiling it sits closest to."""
+    """The contract's roofline block for one kernel (bound = HBM, counter bytes) + what else could bind it under `secondary`."""
     sec = ms * 1e-3
+    unit_item = item_name[:-1]
     out = {"kernel": name, "launches": int(launches), "avg_launch_ms": round(ms / max(1, launches), 4),
            item_name + "_per_launch": round(items / max(1, launches), 1),
            "g%s_per_s" % item_name: round(items / sec / 1e9, 4) if sec > 0 else 0.0}
     alg = items * alg_bytes_per_item / sec / 1e9 if sec > 0 else 0.0
-    ceilings = {}
-    hbm = {"algorithmic_bytes_per_%s" % item_name[:-1]: round(alg_bytes_per_item, 1), "algorithmic_GBs": round(alg, 1),
-           "algorithmic_frac_of_hbm_peak": round(alg / HBM_PEAK_GBS, 4)}
     k = (pmc or {}).get("kernels", {}).get(name)
-    traffic = None
+    secondary = {}
+    achieved, traffic, src = None, None, None
     if k:
         stale = bool(lib_sha and pmc.get("library_sha16") and pmc["library_sha16"] != lib_sha)
         src = {"source": pmc_src, "stale": stale}
         if k.get("hbm_bytes_per_item") is not None:
-            cb = items * k["hbm_bytes_per_item"] / sec / 1e9 if sec > 0 else 0.0
+            achieved = items * k["hbm_bytes_per_item"] / sec / 1e9 if sec > 0 else 0.0
             traffic = k["hbm_bytes_per_item"] * items / max(1, launches)
-            hbm.update({"counter_bytes_per_%s" % item_name[:-1]: round(k["hbm_bytes_per_item"], 1), "counter_GBs": round(cb, 1),
-                        "counter_frac_of_hbm_peak": round(cb / HBM_PEAK_GBS, 4), "fetch_correction": k.get("fetch_correction"), **src})
-            ceilings["hbm"] = (cb, HBM_PEAK_GBS, "GB/s")
+            out["counter_bytes_per_%s" % unit_item] = round(k["hbm_bytes_per_item"], 1)
+            out["fetch_correction"] = k.get("fetch_correction")
+            if k.get("fetch_split"):
+                out["fetch_split"] = {a: round(b, 1) for a, b in k["fetch_split"].items()}
         if k.get("valu_insts_per_item") is not None:
             tl = items * k["valu_insts_per_item"] * 64.0 / sec / 1e12 if sec > 0 else 0.0
-            out["valu"] = {"wave_insts_per_%s" % item_name[:-1]: round(k["valu_insts_per_item"], 1), "achieved_Tlaneops": round(tl, 2),
-                           "peak_Tlaneops": VALU_PEAK_TLOPS, "frac": round(tl / VALU_PEAK_TLOPS, 4), **src}
-            ceilings["valu-issue"] = (tl, VALU_PEAK_TLOPS, "Tlane-op/s")
+            secondary["valu_issue"] = {"wave_insts_per_%s" % unit_item: round(k["valu_insts_per_item"], 1), "achieved_Tlaneops": round(tl, 2),
+                                       "peak_Tlaneops": VALU_PEAK_TLOPS, "frac": round(tl / VALU_PEAK_TLOPS, 4)}
+        if k.get("l1_accesses_per_item") is not None:
+            tg = items * k["l1_accesses_per_item"] / sec / 1e9 if sec > 0 else 0.0
+            secondary["l1_tag_rate"] = {"tag_accesses_per_%s" % unit_item: round(k["l1_accesses_per_item"], 2), "achieved_G_per_s": round(tg, 1),
+                                        "peak_G_per_s": L1_TAG_PEAK_G, "frac": round(tg / L1_TAG_PEAK_G, 4)}
         if k.get("l2_read_requests_per_item") is not None:
             rq = items * k["l2_read_requests_per_item"] / sec / 1e9 if sec > 0 else 0.0
-            out["l2_requests"] = {"per_%s" % item_name[:-1]: round(k["l2_read_requests_per_item"], 2), "achieved_Greq_per_s": round(rq, 2),
-                                  "peak_Greq_per_s": L2_REQ_PEAK_G, "frac": round(rq / L2_REQ_PEAK_G, 4), "l2_hit_rate": k.get("l2_hit_rate"),
-                                  "l1_accesses_per_%s" % item_name[:-1]: k.get("l1_accesses_per_item"), **src}
-            ceilings["l2-request-rate"] = (rq, L2_REQ_PEAK_G, "Greq/s")
-    # bytes the kernel requests from the cache hierarchy (= the algorithmic bytes) against the aggregate L2 bandwidth
-    ceilings["l2"] = (alg, L2_PEAK_GBS, "GB/s")
-    if "hbm" not in ceilings:
-        ceilings["hbm-algorithmic"] = (alg, HBM_PEAK_GBS, "GB/s")
-    out["hbm"] = hbm
-    # the binding ceiling: highest achieved / peak among the physically meaningful ones (an algorithmic-bytes / HBM-peak ratio
-    # above what the counters show only says the bytes were served by L1 / L2 / Infinity Cache, so it is not a candidate when
-    # counter traffic is known)
-    cand = {b: v for b, v in ceilings.items() if b != "hbm-algorithmic"} or ceilings
-    bound = max(cand, key=lambda b: cand[b][0] / cand[b][1])
-    a, p, u = ceilings[bound]
-    out.update({"bound": bound, "achieved": round(a, 2), "peak": p, "unit": u, "frac": round(a / p, 5), "traffic": traffic})
-    if traffic is not None:
-        out["traffic_source"] = pmc_src
+            secondary["l2_request_rate"] = {"requests_per_%s" % unit_item: round(k["l2_read_requests_per_item"], 2), "achieved_Greq_per_s": round(rq, 2),
+                                            "peak_Greq_per_s": L2_REQ_PEAK_G, "frac": round(rq / L2_REQ_PEAK_G, 4), "l2_hit_rate": k.get("l2_hit_rate")}
+    counter_based = achieved is not None
+    if not counter_based:  # no committed counter pass for this workload: the algorithmic figure, labelled as such
+        achieved = alg
+    out.update({"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "achieved_is": "counter bytes (FETCH_SIZE + WRITE_SIZE, corrected) / launch time" if counter_based
+                else "ALGORITHMIC bytes / launch time (no counter pass committed for this workload)",
+                "algorithmic_bytes_per_%s" % unit_item: round(alg_bytes_per_item, 1), "algorithmic_GBs": round(alg, 1)})
+    if counter_based and achieved > 0:
+        out["algorithmic_over_counter"] = round(alg / achieved, 2)
+    if src:
+        out["counters"] = src
+    if secondary:
+        out["secondary"] = secondary
+        out["binding_secondary"] = max(secondary, key=lambda b: secondary[b]["frac"])
     if extra:
         out.update(extra)
     return out
@@ -215,6 +228,14 @@ def main():
 
     factory, W, H, full_spp, B = scenes.CONFIGS[args.workload]
     S, K = args.spp_per_step, args.steps
+    ndev_all = args.gpus if (args.inproc and args.gpus > 1) else world
+    strong_spp = 0
+    if args.strong:
+        # C4: the SAME render (1024 spp on the C3 scene) whatever N is; every device gets spp / N samples
+        strong_spp = args.spp or (1024 if args.workload == "c3" else full_spp)
+        per_dev = -(-strong_spp // ndev_all)
+        S = min(S, per_dev)
+        K = -(-per_dev // S)
     Wu = 0 if args.pmc_pass else args.warmup
     if args.workload == "c5" and not args.c5_in_memory:
         # the C5-class scene enters as FILES through scene ingestion (pt_scene_import_gltf + pt_scene_load_environment): a .glb with
@@ -226,16 +247,22 @@ def main():
         scene = factory()
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    ndev = args.gpus if inproc else 1       # devices driven by THIS process
-    n_gpus = args.gpus if inproc else world
+    ndev = args.gpus if inproc else 1       # devices (group members) driven by THIS process
+    members_all = args.gpus if inproc else world   # shards of the whole job
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)  # the accumulator lives in a torch tensor so RCCL can reduce it
 
     devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(ndev))
     if inproc and len(devices) != ndev:
         raise SystemExit("--devices must list --gpus ordinals")
+    # n_gpus = PHYSICAL devices doing the work: logical shards on one GPU (--devices 0,0 / --rehearse-on-device0) are a rehearsal
+    # of the sharding + merge code, not a multi-GPU measurement, and are labelled as such
+    n_gpus = len(set(devices)) if inproc else (1 if args.rehearse_on_device0 else world)
+    rehearsal = n_gpus != members_all
     r = Renderer(devices=devices) if inproc else Renderer(device=local_rank)
     # samples of this process: K*S per device, timed; the warm-up renders (and discards) W*S of the same range first
     total_spp = K * S * ndev
+    if args.strong:
+        total_spp = -(-strong_spp // ndev_all) * ndev      # (this process's share of the fixed render)
     first, _ = shard_samples(rank, world, total_spp)
     policy = abi.NONFINITE_ZERO
 
@@ -286,7 +313,8 @@ def main():
     r.setProfiling(False)
     elapsed = timed_pass()
     st = r.stats()
-    value = W * H * (K * S) * B * n_gpus / elapsed / 1e6
+    spp_all = total_spp * (1 if inproc else world)   # samples per pixel the whole job accumulated in the timed region
+    value = W * H * spp_all * B / elapsed / 1e6
     mean_radiance = float(acc[..., :3].mean().item())
 
     # ---- kernel pass: the same K steps again with HIP events around every launch (not part of `value`) ----
@@ -312,13 +340,10 @@ def main():
                 lib_sha, {"nodes_per_ray": round(nodes_s, 2), "tris_per_ray": round(tris_s, 2)})
         for name in ("k_trace_closest", "k_trace_shadow"):
             b = blocks.get(name)
-            if b and "counter_frac_of_hbm_peak" in b["hbm"]:
-                b["hbm"]["target_frac"] = HBM_TARGET_FRAC
-                # two readings of the target: the contract's `achieved` (algorithmic bytes / launch time) and the
-                # stricter one on the bytes the HBM counters saw — caches serve most of the algorithmic bytes
-                b["hbm"]["target_met_algorithmic_bytes"] = bool(b["hbm"]["algorithmic_frac_of_hbm_peak"] >= HBM_TARGET_FRAC)
-                b["hbm"]["target_met_counter_bytes"] = bool(b["hbm"]["counter_frac_of_hbm_peak"] >= HBM_TARGET_FRAC)
-                b["hbm"]["target_met"] = b["hbm"]["target_met_counter_bytes"]
+            if b and b.get("traffic") is not None:
+                # north_star: ">= 40 % of HBM peak on the traversal kernel", read on the bytes the HBM counters saw
+                b["target_frac"] = HBM_TARGET_FRAC
+                b["target_met"] = bool(b["frac"] >= HBM_TARGET_FRAC)
     times = {"k_trace_closest": ks.ms_closest, "k_shade": ks.ms_shade, "k_trace_shadow": ks.ms_shadow}
     dominant = max(times, key=times.get) if blocks else None
     roofline = dict(blocks[dominant]) if dominant else None
@@ -334,18 +359,19 @@ def main():
         "warmup": Wu,
         "ms_per_step": round(elapsed / K * 1e3, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
             "workload": WORKLOADS[args.workload],
-            "width": W, "height": H, "max_bounces": B, "spp_per_step": S, "spp_per_gpu": K * S, "spp_total": K * S * n_gpus,
+            "width": W, "height": H, "max_bounces": B, "spp_per_step": S, "spp_per_gpu": total_spp // ndev, "spp_total": spp_all,
             "integrator": "MIS+NEE", "flags": "MultiscatterGGX", "triangles": int(st.triangles),
             "nonfinite_policy": "zero (a NaN/inf sample counts as black; parity default is propagate)",
-            "parallelism": ("sample-sharded x%d, one process, library multi-device + RCCL" % n_gpus) if inproc else
-                           ("sample-sharded x%d, one process per GPU + RCCL all-reduce" % n_gpus) +
-                           (" [REHEARSAL: all ranks on device 0, gloo]" if args.rehearse_on_device0 else ""),
+            "parallelism": (("sample-sharded x%d, one process, library device group%s" % (members_all, " + RCCL all-reduce" if n_gpus > 1 else "")) if inproc else
+                            ("sample-sharded x%d, one process per GPU + RCCL all-reduce" % members_all)) +
+                           ((" [REHEARSAL: %d logical shards on %d physical GPU(s); no RCCL call is made]" % (members_all, n_gpus)) if rehearsal else ""),
+            "logical_shards": members_all,
         },
         "roofline": roofline,
         "roofline_kernels": blocks,
@@ -360,13 +386,14 @@ def main():
                           "note": "separate pass of the same %d steps with HIP events around every launch" % K,
                           "pass_wall_ms": round(elapsed_k * 1e3, 2) if elapsed_k else None},
             "wall_ms": round(elapsed * 1e3, 2),
+            "time_to_image_ms": round(elapsed * 1e3, 2) if args.strong else None,
             "mean_radiance": mean_radiance,
             "library_sha16": lib_sha,
         },
     }
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload (rank 0, N = 1 only) ----
-    if n_gpus == 1 and not args.no_cpu_baseline and not args.pmc_pass:
+    if members_all == 1 and not args.no_cpu_baseline and not args.pmc_pass:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
         from platinum_amd.renderer import make_params

@@ -236,6 +236,10 @@ int pt_create(const pt_create_info* info, pt_renderer** out);
  * [b * ceil(spp / buckets), ...), renderer_pt.cpp:124-126), bucket0/bucket1 = each member's bucket range (may be NULL). */
 int pt_group_partition(uint32_t spp, uint32_t members, int32_t flags, uint32_t gmon_buckets, uint64_t* first, uint64_t* count,
                        uint32_t* bucket0, uint32_t* bucket1);
+/* Loads librccl.so the way a device group over >= 2 distinct GPUs does (dlopen) and binds the entry points the merge uses
+ * (ncclCommInitAll, ncclCommDestroy, ncclAllReduce, ncclGroupStart, ncclGroupEnd, ncclGetErrorString).  No GPU is touched:
+ * a build-box check that the multi-GPU path can find its collective library.  PT_OK or PT_ERR_UNSUPPORTED (pt_last_error). */
+int pt_rccl_probe(void);
 /* Renderer::~Renderer (renderer_pt.hpp:34) */
 void pt_destroy(pt_renderer* r);
 
@@ -263,13 +267,32 @@ typedef struct pt_render_params {
  * of nodes, staged in LDS by the trace kernels); needs invertible instance transforms, else one BVH is built. */
 enum { PT_ACCEL_AUTO = 0, PT_ACCEL_ONE_BVH = 1, PT_ACCEL_TWO_LEVEL = 2 };
 
+/* How pt_start_render sizes the wavefront queues for an image (pure host arithmetic, exported for tests): the samples traced
+ * concurrently per batch after every index-width limit has been applied (an explicit samples_in_flight is HALVED until the
+ * 16-bit segment slots, the 32-bit queue indices and the chunk tables can address the batch; the image does not change),
+ * and the segment geometry.  free_hbm_bytes only matters for samples_in_flight = 0 (auto); tiles_per_seg_override /
+ * seg_bands are the $PTAMD_TILES_PER_SEG / $PTAMD_SEG_BANDS tuning knobs (0 / 4 by default). */
+typedef struct pt_queue_plan {
+  uint32_t samples_in_flight;  /* what a batch will carry */
+  uint32_t tiles_per_seg;      /* 8x8 pixel tiles per queue segment */
+  uint32_t nseg;               /* segments (<= 32768) */
+  uint32_t seg_cap;            /* path slots per segment = tiles_per_seg * samples_in_flight * 64 (<= 65536) */
+  uint64_t capacity;           /* path slots per queue array */
+  uint64_t lbuf_entries;       /* entries of the per-sample radiance buffer */
+} pt_queue_plan;
+int pt_plan_queues(uint32_t width, uint32_t height, uint32_t spp, uint32_t samples_in_flight, uint64_t free_hbm_bytes,
+                   uint32_t tiles_per_seg_override, uint32_t seg_bands, pt_queue_plan* out);
+
 /* Renderer::startRender + the rebuild* half of the first Renderer::render() (renderer_pt.cpp:72-111,
  * 199-217): copies the snapshot to HBM, builds light table, constants and the LBVH.  The caller owns the
  * snapshot memory only until this returns. Resets progress to 0. */
 int pt_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_render_params* params);
 
-/* Renderer::render() steady state (renderer_pt.cpp:113-197): enqueue up to `max_spp_this_call` further
- * samples (the reference encodes exactly 1) and return without waiting. 0 = all remaining samples. */
+/* Renderer::render() steady state (renderer_pt.cpp:113-197): accept up to `max_spp_this_call` further samples (the reference
+ * encodes exactly 1) and return without waiting. 0 = all remaining samples.  Progress counts accepted samples, as the reference's
+ * m_accumulatedFrames counts encoded ones.  Calls that arrive while the GPU is still executing the previous batch are merged into
+ * one batch of up to samples_in_flight samples (a one-sample batch cannot fill the chip); pt_wait, the pt_read_* / present entry
+ * points and the call that accepts the render's last sample enqueue whatever is pending.  The image is the same either way. */
 int pt_render_step(pt_renderer* r, uint32_t max_spp_this_call);
 /* Block until everything enqueued so far has completed (the reference only blocks in readback). */
 int pt_wait(pt_renderer* r);
@@ -381,7 +404,7 @@ typedef struct pt_stats {
   double nodes_per_closest_ray, tris_per_closest_ray;
   double nodes_per_shadow_ray, tris_per_shadow_ray;
   uint32_t accel_two_level;    /* 1: the two-level structure is in use */
-  uint32_t _pad;
+  uint32_t batches;            /* batches enqueued since pt_start_render (pt_render_step calls that arrive while the GPU is busy are merged) */
 } pt_stats;
 int pt_get_stats(pt_renderer* r, pt_stats* out);
 /* Enable per-kernel HIP-event timing (adds two event records per launch). */

@@ -134,6 +134,11 @@ class RenderParams(C.Structure):
     ]
 
 
+class QueuePlan(C.Structure):
+    _fields_ = [("samples_in_flight", C.c_uint32), ("tiles_per_seg", C.c_uint32), ("nseg", C.c_uint32), ("seg_cap", C.c_uint32),
+                ("capacity", C.c_uint64), ("lbuf_entries", C.c_uint64)]
+
+
 class GmonOptions(C.Structure):
     _fields_ = [("cap", C.c_float)]
 
@@ -176,7 +181,7 @@ class Stats(C.Structure):
         ("ms_accumulate", C.c_double), ("launches_closest", C.c_uint64), ("launches_shadow", C.c_uint64),
         ("nodes_per_closest_ray", C.c_double), ("tris_per_closest_ray", C.c_double),
         ("nodes_per_shadow_ray", C.c_double), ("tris_per_shadow_ray", C.c_double),
-        ("accel_two_level", C.c_uint32), ("_pad", C.c_uint32),
+        ("accel_two_level", C.c_uint32), ("batches", C.c_uint32),
     ]
 
 
@@ -189,6 +194,8 @@ SYMBOLS = [
     ("pt_create", C.c_int, [C.POINTER(CreateInfo), C.POINTER(C.c_void_p)]),
     ("pt_group_partition", C.c_int, [C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("pt_rccl_probe", C.c_int, []),
+    ("pt_plan_queues", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(QueuePlan)]),
     ("pt_destroy", None, [C.c_void_p]),
     ("pt_start_render", C.c_int, [C.c_void_p, C.POINTER(SceneSnapshot), C.POINTER(RenderParams)]),
     ("pt_render_step", C.c_int, [C.c_void_p, C.c_uint32]),

@@ -27,6 +27,7 @@
 #include "kernels.h"
 #include "pt_post.h"
 #include "pt_shade.h"
+#include "queue_plan.h"
 
 namespace pt {
 
@@ -69,6 +70,7 @@ __device__ __forceinline__ uint32_t seg_slot(uint32_t nseg, uint32_t s, uint32_t
   return (((k / PT_SEG_GROUP) * nseg + s) * PT_SEG_GROUP + (k % PT_SEG_GROUP)) * 64u + (r & 63u);
 }
 uint32_t seg_group_chunks() { return PT_SEG_GROUP; }
+static_assert(PT_SEG_GROUP == kSegGroupChunks, "queue_plan.h sizes the queue arrays for this interleaving");
 
 // ---- chunk claims for the trace kernels ------------------------------------------------------------------------------
 // 64-ray chunks claimed per cursor atomic.  ONE L2 address sustains ~88 returning atomics per microsecond
@@ -419,6 +421,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
   __shared__ LightRec lds_lights[kShadeLights];
   __shared__ float lds_Eavg[kLutEavg];
   __shared__ float lds_EavgMs[kLutEavgMs * kLutEavgMs];
+  static_assert(kMaxSegmentSlots <= 65536, "slot numbers inside a segment are binned as uint16_t (queue_plan.h bounds seg_cap)");
   __shared__ uint16_t lds_bins[kShadeBlock / 64][5][kBinCap];  // per wave: slot numbers by material class (+ misses), 1.25 KB
   __shared__ uint32_t lds_bin_tri[kShadeBlock / 64][5][kBinCap]; // ... and the triangle hit there: the pass starts its ShadeRec load with the state gather
   const uint32_t halton_base = 5u + 7u * bounce;

@@ -16,6 +16,7 @@
 // on that device; RCCL is only entered with distinct devices, and is loaded (dlopen librccl.so) only then.
 // The reference has no counterpart: it renders on the one MTL::Device of its window (frontend.cpp:138).
 #include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enumerators only: librccl.so itself is loaded with dlopen on first use
 
 #include <algorithm>
 #include <condition_variable>
@@ -29,14 +30,14 @@ namespace {
 
 // ---- one host thread per member ----------------------------------------------------------------------------------------
 struct Worker {
-  std::thread th;
   std::mutex m;
   std::condition_variable cv;
   std::function<int()> job;
   bool has = false, stop = false;
   int rc = PT_OK;
   std::string err;
-  Worker() : th([this] { run(); }) {}
+  std::thread th;  // declared LAST and started in the constructor body: run() must find every other member constructed
+  Worker() { th = std::thread([this] { run(); }); }
   ~Worker() {
     { std::lock_guard<std::mutex> l(m); stop = true; }
     cv.notify_all();
@@ -70,33 +71,40 @@ struct Worker {
 };
 
 // ---- RCCL, loaded on first use -------------------------------------------------------------------------------------------
+// The library is dlopen'ed (a one-GPU host never needs it), but the entry points are typed from the image's own <rccl/rccl.h>,
+// so a changed signature or enumerator is a compile error here instead of a wrong call on an 8-GPU node.
 struct Rccl {
-  typedef void* comm_t;
-  int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
-  int (*CommDestroy)(comm_t) = nullptr;
-  int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
+  typedef ncclComm_t comm_t;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
   void* lib = nullptr;
-  static constexpr int kFloat32 = 7, kSum = 0;  // ncclFloat32, ncclSum (rccl.h)
+  static constexpr ncclDataType_t kFloat32 = ncclFloat32;
+  static constexpr ncclRedOp_t kSum = ncclSum;
   bool load(std::string* why) {
-    if (lib) return true;
-    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (lib) break;
-    }
-    if (!lib) { *why = std::string("cannot load librccl.so: ") + dlerror(); return false; }
-    auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) *why = std::string("librccl.so lacks ") + n; return p; };
+    if (lib && CommInitAll) return true;
+    if (!lib)
+      for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (lib) break;
+      }
+    if (!lib) { const char* e = dlerror(); *why = std::string("cannot load librccl.so: ") + (e ? e : "?"); return false; }
+    bool ok = true;
+    auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) { *why = std::string("librccl.so lacks ") + n; ok = false; } return p; };
     CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
     CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
     AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
     GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
     GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
     GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-    return CommInitAll && CommDestroy && AllReduce && GroupStart && GroupEnd && GetErrorString;
+    if (!ok) CommInitAll = nullptr;
+    return ok;
   }
 };
+static_assert(ncclFloat32 == 7 && ncclSum == 0, "rccl.h enumerators this file was written against");
 Rccl g_rccl;
 std::mutex g_rccl_mutex;
 
@@ -199,21 +207,55 @@ void group_destroy(pt_renderer* front) {
   delete front;
 }
 
-int group_start_render(pt_renderer* front, const pt_scene_snapshot* scene, const pt_render_params* p) {
-  DeviceGroup* grp = front->group;
+// what dev_start_render would reject, checked BEFORE the group's previous render is torn down (renderer.hip dev_start_render)
+int group_validate_params(const pt_scene_snapshot* scene, const pt_render_params* p) {
   if (!scene || !p) return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: null argument");
   if (p->spp == 0 || p->width == 0 || p->height == 0) return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: empty size or spp");
   if (p->stream) return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: a caller stream cannot drive a device group (every member owns its stream)");
+  if (p->max_bounces < 1 || p->max_bounces > 50)
+    return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: max_bounces must be 1..50 (620 Halton dimensions, kernel.metal:5)");
+  if ((uint64_t)p->width * p->height > (1ull << 28)) return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: image too large");
+  if (p->integrator != PT_INTEGRATOR_SIMPLE && p->integrator != PT_INTEGRATOR_MIS) return fail(PT_ERR_INVALID_ARGUMENT, "bad integrator");
+  if (p->nonfinite_policy > PT_NONFINITE_ZERO) return fail(PT_ERR_INVALID_ARGUMENT, "bad nonfinite_policy");
+  if (p->accel_structure > PT_ACCEL_TWO_LEVEL) return fail(PT_ERR_INVALID_ARGUMENT, "bad accel_structure");
+  if ((p->flags & PT_FLAG_GMON) && (p->gmon_buckets < 1 || p->gmon_buckets > 32))
+    return fail(PT_ERR_INVALID_ARGUMENT, "gmon_buckets must be 1..32 (gmon.metal:12 maxBuckets)");
+  if (scene->instance_count && (!scene->instances || !scene->instance_materials || !scene->meshes))
+    return fail(PT_ERR_INVALID_ARGUMENT, "pt_start_render: null scene arrays");
+  return PT_OK;
+}
+
+// a failed (re)start leaves the group with NO render: nothing a later pt_wait / pt_read_* could merge or present
+int group_abandon(DeviceGroup* grp, int rc) {
+  const std::string why = pt_last_error_string();  // (release_images makes HIP calls; keep the first error's text)
+  grp->started = false;
+  grp->dirty = false;
+  for (auto* m : grp->shards) m->started = false;
+  grp->release_images();
+  return fail(rc, why);
+}
+
+int group_start_render(pt_renderer* front, const pt_scene_snapshot* scene, const pt_render_params* p) {
+  DeviceGroup* grp = front->group;
+  {
+    const int rc = group_validate_params(scene, p);
+    if (rc != PT_OK) return rc;  // the previous render (if any) stays as it was
+  }
   const size_t N = grp->shards.size();
   const bool gmon = (p->flags & PT_FLAG_GMON) != 0;
-  if (gmon && (p->gmon_buckets < 1 || p->gmon_buckets > 32)) return fail(PT_ERR_INVALID_ARGUMENT, "gmon_buckets must be 1..32 (gmon.metal:12 maxBuckets)");
-  grp->params = *p;
-  grp->first.assign(N, 0); grp->count.assign(N, 0); grp->bucket0.assign(N, 0); grp->bucket1.assign(N, 0);
+  std::vector<uint64_t> first(N, 0), count(N, 0);
+  std::vector<uint32_t> bucket0(N, 0), bucket1(N, 0);
   {
-    const int rc = pt_group_partition(p->spp, (uint32_t)N, p->flags, p->gmon_buckets, grp->first.data(), grp->count.data(), grp->bucket0.data(), grp->bucket1.data());
+    const int rc = pt_group_partition(p->spp, (uint32_t)N, p->flags, p->gmon_buckets, first.data(), count.data(), bucket0.data(), bucket1.data());
     if (rc != PT_OK) return rc;
   }
+  // from here on the previous render is gone: no member is "started" until the new one is completely set up
+  for (auto* m : grp->shards) { (void)hipSetDevice(m->device); if (m->stream) (void)hipStreamSynchronize(m->stream); m->started = false; }
+  grp->started = false;
+  grp->dirty = false;
   grp->release_images();
+  grp->params = *p;
+  grp->first = first; grp->count = count; grp->bucket0 = bucket0; grp->bucket1 = bucket1;
   const size_t npix = (size_t)p->width * p->height;
   // every member renders its range into an accumulator of its own
   int rc = grp->for_all([grp, scene, p](size_t g) {
@@ -230,29 +272,31 @@ int group_start_render(pt_renderer* front, const pt_scene_snapshot* scene, const
     m->gmon_own_buckets = (p->flags & PT_FLAG_GMON) ? std::max(1u, grp->bucket1[g] - grp->bucket0[g]) : 0;
     return dev_start_render(m, scene, &q);
   });
-  if (rc != PT_OK) return rc;
+  if (rc != PT_OK) return group_abandon(grp, rc);
   // images of the merge
   pt_renderer* m0 = grp->shards[0];
-  PT_HIP(hipSetDevice(m0->device));
+#define PT_GRP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(e_ == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); return group_abandon(grp, e_ == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP); } } while (0)
+  PT_GRP(hipSetDevice(m0->device));
   if (p->external_accumulator) grp->merged = (vec4*)p->external_accumulator;
-  else { PT_HIP(hipMalloc((void**)&grp->merged_own, sizeof(vec4) * npix)); grp->merged = grp->merged_own; }
-  PT_HIP(hipMemset(grp->merged, 0, sizeof(vec4) * npix));
-  if (gmon) PT_HIP(hipMalloc((void**)&grp->gmon_gather, sizeof(vec4) * npix * p->gmon_buckets));
+  else { PT_GRP(hipMalloc((void**)&grp->merged_own, sizeof(vec4) * npix)); grp->merged = grp->merged_own; }
+  PT_GRP(hipMemset(grp->merged, 0, sizeof(vec4) * npix));
+  if (gmon) PT_GRP(hipMalloc((void**)&grp->gmon_gather, sizeof(vec4) * npix * p->gmon_buckets));
   else
     for (auto& pd : grp->phys) {
-      PT_HIP(hipSetDevice(pd.ordinal));
-      PT_HIP(hipMalloc((void**)&pd.scratch, sizeof(vec4) * npix));
+      PT_GRP(hipSetDevice(pd.ordinal));
+      PT_GRP(hipMalloc((void**)&pd.scratch, sizeof(vec4) * npix));
     }
+#undef PT_GRP
   // RCCL communicator over the distinct devices (once per group)
   if (!gmon && grp->phys.size() > 1 && !grp->comms_ready) {
     std::lock_guard<std::mutex> l(g_rccl_mutex);
     std::string why;
-    if (!g_rccl.load(&why)) return fail(PT_ERR_UNSUPPORTED, "device group: " + why);
+    if (!g_rccl.load(&why)) { fail(PT_ERR_UNSUPPORTED, "device group: " + why); return group_abandon(grp, PT_ERR_UNSUPPORTED); }
     std::vector<int> devs;
     for (auto& pd : grp->phys) devs.push_back(pd.ordinal);
     std::vector<Rccl::comm_t> comms(devs.size(), nullptr);
-    const int e = g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data());
-    if (e != 0) return fail(PT_ERR_HIP, std::string("ncclCommInitAll failed: ") + g_rccl.GetErrorString(e));
+    const ncclResult_t e = g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+    if (e != ncclSuccess) { fail(PT_ERR_HIP, std::string("ncclCommInitAll failed: ") + g_rccl.GetErrorString(e)); return group_abandon(grp, PT_ERR_HIP); }
     for (size_t d = 0; d < devs.size(); d++) grp->phys[d].comm = comms[d];
     grp->comms_ready = true;
   }
@@ -290,6 +334,7 @@ int group_merge(pt_renderer* front) {
   uint64_t done = 0;
   for (size_t g = 0; g < N; g++) if (grp->shards[g]->started) done += grp->shards[g]->accumulated;
   if (done == 0) return PT_OK;
+  if (!grp->merged) return fail(PT_ERR_BAD_STATE, "device group: no render in progress");
   if (p.flags & PT_FLAG_GMON) {
     // gather the bucket means every member has touched so far, in bucket order, then resolve on device 0 (gmon.metal:14-55)
     const uint32_t B = p.gmon_buckets, spb = (p.spp + B - 1) / B;
@@ -327,14 +372,14 @@ int group_merge(pt_renderer* front) {
   if (!single) {
     for (auto& pd : grp->phys) { PT_HIP(hipSetDevice(pd.ordinal)); PT_HIP(hipStreamSynchronize(pd.stream)); }
     // the single RCCL reduction of the float accumulation buffer over xGMI
-    int e = g_rccl.GroupStart();
+    ncclResult_t e = g_rccl.GroupStart();
     for (auto& pd : grp->phys) {
-      if (e != 0) break;
+      if (e != ncclSuccess) break;
       PT_HIP(hipSetDevice(pd.ordinal));
       e = g_rccl.AllReduce(pd.scratch, pd.scratch, (size_t)npix * 4, Rccl::kFloat32, Rccl::kSum, pd.comm, pd.stream);
     }
-    const int e2 = g_rccl.GroupEnd();
-    if (e != 0 || e2 != 0) return fail(PT_ERR_HIP, std::string("ncclAllReduce failed: ") + g_rccl.GetErrorString(e != 0 ? e : e2));
+    const ncclResult_t e2 = g_rccl.GroupEnd();
+    if (e != ncclSuccess || e2 != ncclSuccess) return fail(PT_ERR_HIP, std::string("ncclAllReduce failed: ") + g_rccl.GetErrorString(e != ncclSuccess ? e : e2));
   }
   PT_HIP(hipSetDevice(m0->device));
   uint32_t active = 0;
@@ -402,8 +447,11 @@ int pt_group_partition(uint32_t spp, uint32_t members, int32_t flags, uint32_t g
     // whole buckets per member: bucket b holds the samples [b * spb, (b + 1) * spb) (renderer_pt.cpp:124-126)
     if (gmon_buckets < 1 || gmon_buckets > 32) return fail(PT_ERR_INVALID_ARGUMENT, "gmon_buckets must be 1..32 (gmon.metal:12 maxBuckets)");
     const uint32_t B = gmon_buckets, spb = (spp + B - 1) / B;
+    // B / members buckets each, the remainder to the LOWEST-numbered members: member 0 — whose device resolves, post-processes and
+    // presents the image — owns a bucket whenever anybody does (5..7 buckets on 8 devices: members 0..B-1 get one each)
+    const uint32_t per = B / members, extra = B % members;
     for (uint32_t g = 0; g < members; g++) {
-      const uint32_t b0 = (uint32_t)((uint64_t)g * B / members), b1 = (uint32_t)((uint64_t)(g + 1) * B / members);
+      const uint32_t b0 = g * per + std::min(g, extra), b1 = b0 + per + (g < extra ? 1u : 0u);
       const uint64_t s0 = std::min<uint64_t>((uint64_t)b0 * spb, spp), s1 = std::min<uint64_t>((uint64_t)b1 * spb, spp);
       if (bucket0) bucket0[g] = b0;
       if (bucket1) bucket1[g] = b1;
@@ -419,6 +467,13 @@ int pt_group_partition(uint32_t spp, uint32_t members, int32_t flags, uint32_t g
       at += c;
     }
   }
+  return PT_OK;
+}
+
+int pt_rccl_probe(void) {
+  std::lock_guard<std::mutex> l(g_rccl_mutex);
+  std::string why;
+  if (!g_rccl.load(&why)) return fail(PT_ERR_UNSUPPORTED, why);
   return PT_OK;
 }
 

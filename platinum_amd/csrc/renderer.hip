@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 
+#include "queue_plan.h"
 #include "renderer_state.h"
 
 using namespace pt;
@@ -56,6 +57,9 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
   const DeviceScene& S = r->S;
   hipStream_t s = r->stream;
   BatchCounters* ctr = r->ctr.p;
+  // the per-bounce hit log is indexed by pixel through pixel_of_pid_1spp (kernels.hip): it only exists for one-sample batches
+  if (hitlog && ns != 1) return fail(PT_ERR_INVALID_ARGUMENT, "the hit log is kept for one-sample batches only");
+  if (ns == 0 || ns > r->samples_in_flight) return fail(PT_ERR_INVALID_ARGUMENT, "batch larger than the queues");
   PT_HIP(hipMemsetAsync(ctr, 0, sizeof(BatchCounters), s));
   const bool count = mode == BATCH_MEASURE;
   Segments seg = r->segments();
@@ -164,6 +168,14 @@ int build_halton_table(pt_renderer* r) {
 
 extern "C" const char* pt_last_error(void) { return g_last_error.c_str(); }
 
+extern "C" int pt_plan_queues(uint32_t width, uint32_t height, uint32_t spp, uint32_t samples_in_flight, uint64_t free_hbm_bytes,
+                              uint32_t tiles_per_seg_override, uint32_t seg_bands, pt_queue_plan* out) {
+  if (!out) return fail(PT_ERR_INVALID_ARGUMENT, "pt_plan_queues: null argument");
+  const char* why = "";
+  const int rc = plan_queues(width, height, spp, samples_in_flight, free_hbm_bytes, tiles_per_seg_override, seg_bands, out, &why);
+  return rc == PT_OK ? PT_OK : fail(rc, std::string("pt_plan_queues: ") + why);
+}
+
 int dev_create(const pt_create_info* info, int device_ordinal, pt_renderer** out) {
   if (!info || !out) return fail(PT_ERR_INVALID_ARGUMENT, "pt_create: null argument");
   *out = nullptr;
@@ -189,6 +201,7 @@ int dev_create(const pt_create_info* info, int device_ordinal, pt_renderer** out
   do {
     if (hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(PT_ERR_HIP, "hipStreamCreate failed"); break; }
     r->stream = r->own_stream;
+    if (hipEventCreateWithFlags(&r->batch_done, hipEventDisableTiming) != hipSuccess) { rc = fail(PT_ERR_HIP, "hipEventCreate failed"); break; }
     std::vector<uint8_t> file;
     const uint8_t* blob = (const uint8_t*)info->lut_blob;
     size_t size = (size_t)info->lut_blob_size;
@@ -221,6 +234,7 @@ void dev_destroy(pt_renderer* r) {
   if (r->stream) (void)hipStreamSynchronize(r->stream);
   r->drop_timed();
   r->free_scene();
+  if (r->batch_done) (void)hipEventDestroy(r->batch_done);
   if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
   delete r;
 }
@@ -379,42 +393,28 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
 
   // ---- wavefront buffers ----
   const uint64_t npix = (uint64_t)p->width * p->height;
-  uint32_t sif = p->samples_in_flight;
-  if (sif == 0) {
-    // As many samples of the frame in flight as a quarter of the free HBM holds (~200 B of queue state per path), up to
-    // 64: the deep bounces of a batch carry few rays, and only a big batch keeps those launches wide enough for 6144
-    // persistent waves (measured on C2: 8 samples in flight 7290, 32: 8440, 64: 8680 Msamples/s; 64 x 1080p = 25 GB).
+  // Queue segments (kernels.hip): one per 8x8 tile (a few tiles each once the image has more than 32640 of them), each with
+  // room for its tiles under all samples in flight; queue_plan.h holds the sizing and every index-width limit.  The producers
+  // (raygen, shade) are persistent grids whose waves take segments round-robin; the trace kernels claim chunks from a table,
+  // so every grid is sized for its own kernel's occupancy.
+  {
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 8ull << 30;
-    sif = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (free_b / 4) / (npix * 200ull)));
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    pt_queue_plan plan{};
+    const char* why = "";
+    const int rc = plan_queues(p->width, p->height, p->spp, p->samples_in_flight, free_b, r->tiles_per_seg_override, r->seg_bands, &plan, &why);
+    if (rc != PT_OK) return fail(rc, std::string("pt_start_render: ") + why);
+    r->samples_in_flight = plan.samples_in_flight;
+    r->tiles_per_seg = plan.tiles_per_seg;
+    r->nseg = plan.nseg;
+    r->seg_cap = plan.seg_cap;
+    r->capacity = (size_t)plan.capacity;
   }
-  sif = std::min<uint32_t>(std::min<uint32_t>(sif, p->spp), 256);
-  {  // the queue slots and the per-sample radiance buffer are indexed with 32 bits (kernels.hip seg_slot, lbuf_index)
-    const uint64_t tiles = (uint64_t)((p->width + 7) / 8) * ((p->height + 7) / 8);
-    while (sif > 1 && tiles * 64 * sif >= (1ull << 31)) sif /= 2;
-    if (tiles * 64 * sif >= (1ull << 31)) return fail(PT_ERR_UNSUPPORTED, "pt_start_render: the image is too large for the 32-bit queue indices");
-  }
-  r->samples_in_flight = sif;
-  // Queue segments (kernels.hip): one per 8x8 tile (a few tiles each once the image has more than 32768 of them), each with
-  // room for its tiles under all samples in flight.  The producers (raygen, shade) are persistent grids whose waves take
-  // segments round-robin; the trace kernels claim chunks from a table, so every grid is sized for its own kernel's occupancy.
+  const uint32_t sif = r->samples_in_flight;
   r->grid = (uint32_t)r->num_cu * r->blocks_per_cu;                 // raygen, hit records: 256-thread blocks
   r->shade_grid = (uint32_t)r->num_cu * shade_blocks_per_cu();     // as many blocks as k_shade's registers / LDS keep resident
   r->trace_grid = r->two_level ? (uint32_t)r->num_cu * trace_blocks_per_cu_two_level() : (uint32_t)r->num_cu * r->trace_blocks_per_cu;
-  {
-    const uint64_t tiles = (uint64_t)((p->width + 7) / 8) * ((p->height + 7) / 8);
-    r->tiles_per_seg = (uint32_t)((tiles + 32639) / 32640);  // nseg <= 32768 after rounding up to a multiple of the band count
-    if (r->tiles_per_seg_override) r->tiles_per_seg = std::max(r->tiles_per_seg, r->tiles_per_seg_override);
-    r->nseg = (uint32_t)((tiles + r->tiles_per_seg - 1) / r->tiles_per_seg);
-    r->nseg = (r->nseg + r->seg_bands - 1) / r->seg_bands * r->seg_bands;  // (segments past the last tile stay empty)
-    if ((uint64_t)r->tiles_per_seg * sif >= 32768) return fail(PT_ERR_INVALID_ARGUMENT, "image x samples_in_flight too large for the chunk tables");
-    r->seg_cap = r->tiles_per_seg * sif * 64;
-    r->nstats = std::max(r->grid * (kBlock / 64), r->shade_grid * (shade_block_threads() / 64));
-  }
-  {
-    const uint32_t G = seg_group_chunks(), K = r->seg_cap / 64;
-    r->capacity = (size_t)r->nseg * ((K + G - 1) / G * G) * 64;  // >= npix * sif
-  }
+  r->nstats = std::max(r->grid * (kBlock / 64), r->shade_grid * (shade_block_threads() / 64));
   for (int k = 0; k < 2; k++) {
     PT_HIP(r->st_rayO[k].alloc(r->capacity)); PT_HIP(r->st_rayD[k].alloc(r->capacity));
     PT_HIP(r->st_att[k].alloc(r->capacity));
@@ -445,6 +445,9 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
 
   for (int k = 0; k < K_CLASSES; k++) { r->ms_class[k] = 0; r->launches[k] = 0; }
   r->accumulated = 0;
+  r->launched = 0;
+  r->batches = 0;
+  r->batch_done_valid = false;
   r->total = p->spp;
   r->started = true;
   r->render_start = std::chrono::steady_clock::now();
@@ -452,26 +455,44 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   return PT_OK;
 }
 
+// Enqueues accepted-but-pending samples.  The reference's frontend calls render() once per UI frame for exactly ONE sample
+// (renderer_pt.cpp:131-153, frontend.cpp:209-210); a one-sample batch leaves the deep bounces of the wavefront too narrow for the
+// chip (C3: 1 in flight runs at about a third of the 64-in-flight rate).  So a step that arrives while the previous batch is
+// still executing is not enqueued on its own: it waits until the GPU has drained (then everything pending goes out as ONE batch)
+// or until a full batch of `samples_in_flight` has gathered (enqueued behind the running one, so the GPU never idles).  A caller
+// slower than the GPU gets exactly the old behaviour (one batch per call); a tight render() loop converges to full batches.
+// The image does not depend on the batching: k_accumulate folds samples in index order.  `all`: enqueue everything now.
+int flush_pending(pt_renderer* r, bool all) {
+  while (r->launched < r->accumulated) {
+    const uint64_t pending = r->accumulated - r->launched;
+    const bool idle = !r->batch_done_valid || hipEventQuery(r->batch_done) == hipSuccess;
+    if (!all && !idle && pending < r->samples_in_flight) break;
+    const uint32_t ns = (uint32_t)std::min<uint64_t>(pending, r->samples_in_flight);
+    const int rc = enqueue_batch(r, r->params.first_sample + (uint32_t)r->launched, ns, (uint32_t)r->launched, BATCH_RENDER, nullptr);
+    if (rc != PT_OK) return rc;
+    r->launched += ns;
+    r->batches++;
+    if (r->batch_done && hipEventRecord(r->batch_done, r->stream) == hipSuccess) r->batch_done_valid = true;
+  }
+  return PT_OK;
+}
+
 int dev_render_step(pt_renderer* r, uint32_t max_spp) {
   if (!r) return fail(PT_ERR_INVALID_ARGUMENT, "null renderer");
   if (!r->started) return fail(PT_ERR_BAD_STATE, "pt_render_step before pt_start_render");
   PT_HIP(hipSetDevice(r->device));
-  uint64_t remaining = r->total - r->accumulated;
-  uint64_t n = max_spp == 0 ? remaining : std::min<uint64_t>(max_spp, remaining);
-  while (n > 0) {
-    const uint32_t ns = (uint32_t)std::min<uint64_t>(n, r->samples_in_flight);
-    int rc = enqueue_batch(r, r->params.first_sample + (uint32_t)r->accumulated, ns, (uint32_t)r->accumulated, BATCH_RENDER, nullptr);
-    if (rc != PT_OK) return rc;
-    r->accumulated += ns;
-    n -= ns;
-  }
+  const uint64_t remaining = r->total - r->accumulated;
+  r->accumulated += max_spp == 0 ? remaining : std::min<uint64_t>(max_spp, remaining);
+  // the last samples of the render go out at once: nothing is ever pending while status() reports Done
+  const int rc = flush_pending(r, r->accumulated == r->total);
   r->timer_ms = (uint64_t)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r->render_start).count();
-  return PT_OK;
+  return rc;
 }
 
 int dev_wait(pt_renderer* r) {
   if (!r) return fail(PT_ERR_INVALID_ARGUMENT, "null renderer");
   PT_HIP(hipSetDevice(r->device));
+  if (r->started) { const int rc = flush_pending(r, true); if (rc != PT_OK) return rc; }
   PT_HIP(hipStreamSynchronize(r->stream));
   collect_timings(r);
   if (r->started)
@@ -569,6 +590,7 @@ int dev_present(pt_renderer* r, const vec4* acc_device, void** device_rgba8_out,
   if (!r || !device_rgba8_out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   if (!r->started) return fail(PT_ERR_BAD_STATE, "pt_present_render_target before pt_start_render");
   PT_HIP(hipSetDevice(r->device));
+  { const int rc = flush_pending(r, true); if (rc != PT_OK) return rc; }  // the image shows every sample accepted so far
   const size_t npix = (size_t)r->S.width * r->S.height;
   if (r->render_target.n != npix) PT_HIP(r->render_target.alloc(npix));
   PostConstants pc;
@@ -641,6 +663,7 @@ int dev_trace_primary(pt_renderer* r, uint32_t sample_idx, pt_hit_record* out) {
   if (!r || !out) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
   PT_HIP(hipSetDevice(r->device));
+  { const int rc = flush_pending(r, true); if (rc != PT_OK) return rc; }
   const uint32_t npix = r->S.width * r->S.height;
   DevBuf<pt_hit_record> rec;
   PT_HIP(rec.alloc(npix));
@@ -663,6 +686,7 @@ int dev_debug_sample(pt_renderer* r, uint32_t sample_idx, float* radiance_out, i
   if (!r) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
   PT_HIP(hipSetDevice(r->device));
+  { const int rc = flush_pending(r, true); if (rc != PT_OK) return rc; }
   const size_t npix = (size_t)r->S.width * r->S.height;
   DevBuf<int32_t> log;
   if (hits_out) {
@@ -692,6 +716,7 @@ int dev_measure_traversal(pt_renderer* r, uint32_t sample_idx) {
   if (!r) return fail(PT_ERR_INVALID_ARGUMENT, "null argument");
   if (!r->started) return fail(PT_ERR_BAD_STATE, "no render started");
   PT_HIP(hipSetDevice(r->device));
+  { const int rc = flush_pending(r, true); if (rc != PT_OK) return rc; }
   const bool prof = r->profiling;
   r->profiling = false;
   int rc = enqueue_batch(r, sample_idx, 1, 0, BATCH_MEASURE, nullptr);
@@ -729,6 +754,7 @@ int dev_get_stats(pt_renderer* r, pt_stats* out) {
   out->ms_raygen = r->ms_class[K_RAYGEN]; out->ms_closest = r->ms_class[K_CLOSEST]; out->ms_shade = r->ms_class[K_SHADE];
   out->ms_shadow = r->ms_class[K_SHADOW]; out->ms_accumulate = r->ms_class[K_ACCUM];
   out->accel_two_level = r->two_level ? 1u : 0u;
+  out->batches = r->batches;
   out->launches_closest = r->launches[K_CLOSEST];
   out->launches_shadow = r->launches[K_SHADOW];
   if (t.counted_closest) {

@@ -124,8 +124,13 @@ struct pt_renderer {
   uint32_t gmon_own_buckets = 0;   // buckets it owns; 0 = params.gmon_buckets
   struct DeviceGroup* group = nullptr;  // non-null on the front object of a device group
 
-  // progress (renderer_pt.hpp:168-171)
-  uint64_t accumulated = 0, total = 0;
+  // progress (renderer_pt.hpp:168-171).  `accumulated` counts the samples pt_render_step has ACCEPTED (what the reference's
+  // m_accumulatedFrames counts: encoded, not finished); `launched` of them are enqueued on the stream, the rest are pending:
+  // render() calls that arrive while the GPU is still busy are merged into one batch (renderer.hip flush_pending).
+  uint64_t accumulated = 0, total = 0, launched = 0;
+  uint32_t batches = 0;                 // batches enqueued since pt_start_render
+  hipEvent_t batch_done = nullptr;      // recorded behind the newest batch
+  bool batch_done_valid = false;
   std::chrono::steady_clock::time_point render_start;
   uint64_t timer_ms = 0;
 

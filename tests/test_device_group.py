@@ -46,6 +46,28 @@ def test_partition_follows_gmon_bucket_boundaries():
     assert lib.pt_group_partition(16, 2, flags, 33, (C.c_uint64 * 2)(), (C.c_uint64 * 2)(), None, None) != 0
 
 
+def test_partition_with_fewer_buckets_than_members_starts_at_member_zero():
+    """The reference UI allows 5..25 buckets (pt_viewport.cpp), so 5..7 buckets on 8 GPUs happens: the remainder buckets go to
+    the LOWEST-numbered members — member 0, whose device resolves / post-processes / presents the image, always has samples."""
+    flags = abi.FLAG_MULTISCATTER_GGX | abi.FLAG_GMON
+    for spp, buckets, n in [(128, 5, 8), (128, 7, 8), (64, 6, 8), (12, 4, 8), (30, 15, 8), (9, 1, 4)]:
+        first, count, b0, b1 = _partition(spp, n, flags, buckets)
+        owned = [b1[g] - b0[g] for g in range(n)]
+        assert sum(owned) == buckets and owned == sorted(owned, reverse=True) and max(owned) - min(owned) <= 1
+        assert count[0] > 0 and owned[0] >= 1
+        assert all(count[g] == 0 for g in range(n) if owned[g] == 0)
+
+
+def test_rccl_library_loads_and_exports_the_entry_points_the_merge_calls():
+    """multi_device.hip dlopens librccl.so on first use by a group over >= 2 distinct GPUs; that moment never comes on a
+    one-GPU box, so the load + symbol binding is checked here (no GPU is touched).  The function-pointer types and the
+    ncclFloat32 / ncclSum values are checked at COMPILE time against the image's <rccl/rccl.h>."""
+    lib = abi.load_library()
+    rc = lib.pt_rccl_probe()
+    assert rc == 0, lib.pt_last_error()
+    assert lib.pt_rccl_probe() == 0  # idempotent
+
+
 W, H, B = 96, 64, 5
 
 
@@ -129,6 +151,50 @@ def test_gmon_buckets_map_to_members_and_resolve_bit_identically(spp, buckets, s
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
         img = rn.readbackRenderTarget()
         assert img.shape == (H, W, 4) and img[..., 3].min() == 255
+    finally:
+        rn.close()
+
+
+@pytest.mark.gpu
+def test_failed_restart_leaves_the_group_without_a_render():
+    """a restart that fails validation must not leave members of the PREVIOUS render 'started' beside freed merge
+    images (pt_wait would then launch the merge kernel on null scratch).  Invalid parameters are refused before anything is
+    torn down; a failure past that point abandons the render as a whole."""
+    sc = scenes.cornell_scene("bench")
+    r = Renderer(devices=[0, 0])
+    try:
+        r.startRender(sc, (W, H), 4, max_bounces=B)
+        r.render(2)
+        with pytest.raises(abi.PtamdError):
+            r.startRender(sc, (W, H), 4, max_bounces=51)       # refused up front: the first render is untouched
+        first = r.readbackAccumulator()
+        assert np.isfinite(first).all() and first[..., :3].max() > 0
+        r.render(0)
+        done = r.readbackAccumulator()
+        with pytest.raises(abi.PtamdError):
+            r.startRender(sc, (W, H), 4, max_bounces=B, accel_structure=7)
+        np.testing.assert_array_equal(r.readbackAccumulator(), done)
+        # a restart that is valid still works afterwards
+        r.startRender(sc, (W, H), 2, max_bounces=B)
+        r.render(0)
+        assert r.renderProgress() == (2, 2) and np.isfinite(r.readbackAccumulator()).all()
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("buckets", [5, 7])
+def test_gmon_with_fewer_buckets_than_members_presents_on_the_first_device(buckets):
+    sc = scenes.cornell_sphere_scene()
+    flags = abi.FLAG_MULTISCATTER_GGX | abi.FLAG_GMON
+    spp = 2 * buckets
+    ref, _, r1 = _render(None, sc, spp, gmonBuckets=buckets, flags=flags, samples_in_flight=4)
+    ref_img = r1.readbackRenderTarget()
+    r1.close()
+    got, _, rn = _render([0] * 8, sc, spp, gmonBuckets=buckets, flags=flags, samples_in_flight=4)
+    try:
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+        assert np.array_equal(rn.readbackRenderTarget(), ref_img)
     finally:
         rn.close()
 

@@ -6,9 +6,9 @@ as small fixtures under tests/golden/.  Re-running must reproduce the files bit-
 
   sampler_kat.json        integer known-answers of pcg4d / Halton offset (computed from
                           samplers.metal:16-23,154-156 by the surveyor) + Halton values of the first dims
-  c1_cornell_golden.npz   C1 (Cornell 512x512, 4 bounces, MIS): 64x64 centre crop of the accumulator at 1 and 4 spp,
-                          per-channel means and a sha256 of the full images; primary-ray (instance, primitive) map
-                          checksum and a 64x64 crop of (t,u,v)
+  c1_cornell_golden.npz   C1 (Cornell 512x512, 4 bounces, MIS): 64x64 centre crop of the accumulator at 1, 4 and 64 spp (64 = the
+                          full BASELINE.json configs[0]), per-channel means and a sha256 of the full images; primary-ray
+                          (instance, primitive) map checksum and a 64x64 crop of (t,u,v)
   c2_small_golden.npz     Cornell + glass sphere, 160x90, 8 bounces: full accumulator at 2 spp + per-bounce hit ids of sample 0
   mikkt_tangents.npz      tangents of five meshes computed by the REFERENCE's deps/mikkt/mikktspace.c (compiled where it lies into
                           oracle/_ref/libmikkt.so) through the callbacks of core/mesh.cpp:11-57
@@ -50,10 +50,12 @@ W = H = 512
 o = oracle_lib.OracleScene(sc, make_params(W, H, 4, 4))
 acc1 = o.render(0, 1)
 acc4 = o.render(1, 3, acc=acc1.copy(), acc_n0=1)
+acc64 = o.render(4, 60, acc=acc4.copy(), acc_n0=4)   # the parity gate is C1 at 1 / 4 / 64 spp
 prim = o.trace_primary(0)
 c = slice(224, 288)
 np.savez_compressed(os.path.join(G, "c1_cornell_golden.npz"),
                     acc1_crop=acc1[c, c], acc4_crop=acc4[c, c], acc1_mean=acc1[..., :3].mean((0, 1)), acc4_mean=acc4[..., :3].mean((0, 1)),
+                    acc64_crop=acc64[c, c], acc64_mean=acc64[..., :3].mean((0, 1)), acc64_sha=sha(acc64),
                     acc1_sha=sha(acc1), acc4_sha=sha(acc4), prim_ids_sha=sha(np.stack([prim["instance"], prim["primitive"]], -1)),
                     prim_tuv_crop=np.stack([prim["t"], prim["u"], prim["v"]], -1)[c, c], prim_ids_crop=np.stack([prim["instance"], prim["primitive"]], -1)[c, c])
 # ---- small C2 ----

@@ -4,7 +4,8 @@
   <tag>_<wl>_kernel_stats.csv   copy of rocprofv3 --kernel-trace --stats of the default bench command
   <tag>_<wl>_summary.md         per kernel: calls / avg ms (trace pass); FETCH_SIZE, WRITE_SIZE per launch and per work item,
                                 VALU wave-instructions per work item (--pmc passes of `bench.py --pmc-pass`: full-size batches only)
-  r02_pmc_<wl>.json             what bench.py reads: per-work-item HBM bytes and VALU instructions + the library's sha
+  <round>_pmc_<wl>.json         what bench.py reads: per-work-item HBM bytes and VALU instructions + the library's sha
+                                (<round> = the tag up to its first letter suffix: r03b -> r03)
 
 Units and corrections as MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports
 half of the bytes of wide coalesced streaming reads.  The factor is CALIBRATED here on the two kernels whose byte counts
@@ -109,12 +110,17 @@ if "k_raygen" in write and itw:
 ff = calib.get("fetch_streaming_factor") or 2.0
 # Random 64-byte gathers (what the traversal kernels fetch) are reported exactly: profiles/r02_calib_gather.md
 GATHER_FACTOR = {"k_trace_closest": 1.0, "k_trace_shadow": 1.0, "k_trace_closest[two-level]": 1.0, "k_trace_shadow[two-level]": 1.0}
+# k_shade reads BOTH kinds: per hit it streams its queue entry (hit 16 B + rayO 16 + rayD 16 + att 16 + the 4-byte
+# class word of the scan = 68 B, coalesced dwordx4 / dword runs: reported at 1/ff) and gathers ShadeRec, vertices, material, LUT
+# texels (random records: reported exactly).  true fetch = stream + (raw - stream / ff), bounded below by raw (everything x1)
+# and above by ff * raw (everything xff).
+STREAM_IN_BYTES = {"k_shade": 68.0}
 
 lines = [f"# rocprofv3 summary — bench.py --workload {wl} (MI355X, {tag})", "",
          "Durations: `rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --no-cpu-baseline` (both of bench.py's passes)." % wl,
          "Counters: separate `--pmc` passes of `bench.py --workload %s --pmc-pass --steps 2` (full 64-spp batches only)." % wl, "",
          "Calibration on known byte counts: " + json.dumps({k: (round(v, 4) if isinstance(v, float) and v < 100 else v) for k, v in calib.items()}), "",
-         "| kernel | calls | total ms | avg ms | FETCH raw MiB/launch | FETCH corrected MiB/launch (x%.2f streams, x1 gathers: r02_calib_gather.md) | WRITE MiB/launch | HBM B/item (corr.) | VALU wave-insts/item | items |" % ff,
+         "| kernel | calls | total ms | avg ms | FETCH raw MiB/launch | FETCH corrected MiB/launch (x%.2f streams, x1 gathers, k_shade split: r02_calib_gather.md) | WRITE MiB/launch | HBM B/item (corr.) | VALU wave-insts/item | items |" % ff,
          "|---|---|---|---|---|---|---|---|---|---|"]
 pmc = {"source": f"rocprofv3 --pmc passes of `bench.py --workload {wl} --pmc-pass --steps 2` ({tag}); tools/summarize_prof.py",
        "calibration": calib, "kernels": {}}
@@ -132,6 +138,14 @@ for k in names:
     ni_f, ni_w, ni_s = itf.get(k), itw.get(k), its.get(k)
     kf = GATHER_FACTOR.get(k, ff)
     per_item = (kf * fv * 1024.0 / ni_f + wv * 1024.0 / ni_w) if (ni_f and ni_w and fn and wn) else None
+    split = None
+    if per_item is not None and k in STREAM_IN_BYTES:
+        raw_pi, wr_pi, st = fv * 1024.0 / ni_f, wv * 1024.0 / ni_w, STREAM_IN_BYTES[k]
+        fetch_true = st + max(0.0, raw_pi - st / ff)
+        split = {"stream_in_bytes_per_item": st, "gather_bytes_per_item": max(0.0, raw_pi - st / ff),
+                 "hbm_bytes_per_item_all_x1": raw_pi + wr_pi, "hbm_bytes_per_item_all_streams": ff * raw_pi + wr_pi}
+        per_item = fetch_true + wr_pi
+        kf = fetch_true / raw_pi if raw_pi else kf
     valu = vv / ni_s if (ni_s and vn) else None
     avg = d["total_ms"] / d["calls"] if d["calls"] else float("nan")
     lines.append(f"| {k} | {d['calls']} | {d['total_ms']:.3f} | {avg:.4f} | {fl:.1f} | {kf*fl:.1f} | {wr:.1f} | "
@@ -139,6 +153,14 @@ for k in names:
     if per_item is not None or valu is not None:
         e = {"hbm_bytes_per_item": per_item, "fetch_bytes_raw_per_item": fv * 1024.0 / ni_f if (ni_f and fn) else None,
              "write_bytes_per_item": wv * 1024.0 / ni_w if (ni_w and wn) else None, "fetch_correction": kf, "valu_insts_per_item": valu}
+        if split:
+            e["fetch_split"] = split
+        if d["calls"] and k in summary:
+            e["avg_launch_ms_trace_pass"] = d["total_ms"] / d["calls"]
+        if ni_f and fn:
+            e["fetch_bytes_per_launch_corrected"] = kf * fv * 1024.0 / fn
+            e["write_bytes_per_launch"] = wv * 1024.0 / wn if wn else None
+            e["items_per_launch"] = ni_f / fn
         if k in sq:
             for c in ("SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY"):
                 if c in sq[k] and ni_s:
@@ -152,5 +174,7 @@ for k in names:
         pmc["kernels"][k] = e
 open(os.path.join(out_dir, f"{tag}_{wl}_summary.md"), "w").write("\n".join(lines) + "\n")
 if pmc["kernels"]:
-    json.dump(pmc, open(os.path.join(out_dir, f"r02_pmc_{wl}.json"), "w"), indent=1)
+    import re
+    rnd = re.match(r"(r\d+)", tag).group(1) if re.match(r"(r\d+)", tag) else tag
+    json.dump(pmc, open(os.path.join(out_dir, f"{rnd}_pmc_{wl}.json"), "w"), indent=1)
 print("\n".join(lines))
