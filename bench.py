@@ -90,6 +90,9 @@ def parse_args(argv=None):
                     help="under rocprofv3 --pmc: only full-size batches (no warm-up, no instrumented sample, no CPU leg, no event timing)")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the second (event-timed) pass")
     ap.add_argument("--c5-in-memory", action="store_true", help="c5: the procedural snapshot directly instead of the .glb + .exr ingestion path")
+    ap.add_argument("--drop-in-loop", action="store_true",
+                    help="the reference frontend's call pattern: the timed region calls render() for ONE sample at a time (renderer_pt.cpp:131-153), "
+                         "steps x spp-per-step times, instead of one call per step; samples_in_flight stays spp-per-step")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: a FIXED render of --spp samples per pixel split over the N GPUs (BASELINE.json configs[3], C4: "
                          "`--gpus 8 --strong --spp 1024` = 8 x 128, one reduce); --steps is derived = ceil(spp / N / spp-per-step); reports time to image")
@@ -281,8 +284,12 @@ def main():
     def timed_pass():
         sync()
         t0 = time.perf_counter()
-        for _ in range(K):
-            r.render(S * ndev)
+        if args.drop_in_loop:
+            for _ in range(K * S):
+                r.render(ndev)                 # one sample (per device) per call, as Frontend::start does once per UI frame
+        else:
+            for _ in range(K):
+                r.render(S * ndev)
         r.wait()                               # (--inproc: includes the library's RCCL all-reduce of the per-device accumulators)
         reduce_accumulator(acc, world, dist)   # one process per GPU: the single RCCL sum-reduce of the accumulation buffer
         sync()
@@ -367,6 +374,8 @@ def main():
             "workload": WORKLOADS[args.workload],
             "width": W, "height": H, "max_bounces": B, "spp_per_step": S, "spp_per_gpu": total_spp // ndev, "spp_total": spp_all,
             "integrator": "MIS+NEE", "flags": "MultiscatterGGX", "triangles": int(st.triangles),
+            "call_pattern": "render(1) per call, merged by the library (reference frontend loop)" if args.drop_in_loop else "render(spp_per_step) per step",
+            "batches": int(st.batches),
             "nonfinite_policy": "zero (a NaN/inf sample counts as black; parity default is propagate)",
             "parallelism": (("sample-sharded x%d, one process, library device group%s" % (members_all, " + RCCL all-reduce" if n_gpus > 1 else "")) if inproc else
                             ("sample-sharded x%d, one process per GPU + RCCL all-reduce" % members_all)) +

@@ -127,6 +127,37 @@ def test_accumulator_matches_oracle_c1_small(gpu_renderer):
     assert (st.closest_rays, st.shadow_rays, st.shaded_hits, st.paths) == (so.closest_rays, so.shadow_rays, so.shaded_hits, so.paths)
 
 
+def test_one_sample_render_calls_are_merged_into_batches_and_give_the_same_image(gpu_renderer):
+    """The reference's frontend calls render() once per UI frame for ONE sample (renderer_pt.cpp:131-153, frontend.cpp:209-210).
+    Calls that arrive while the GPU is busy are merged into batches (renderer.hip flush_pending); the accumulator is
+    bit-identical to one big step, progress counts accepted samples, and nothing stays pending once the render is Done."""
+    sc = _scene("cornell_sphere")
+    w, h, spp, B = 320, 180, 48, 6
+    r = gpu_renderer
+    _start(r, sc, w, h, spp, B, samples_in_flight=16)
+    r.render(0)
+    ref = r.readbackAccumulator()
+    ref_batches = r.stats().batches
+    assert ref_batches == 3
+    _start(r, sc, w, h, spp, B, samples_in_flight=16)
+    n = 0
+    while r.status() & abi.STATUS_BUSY:      # the frontend's loop, as fast as the host can call
+        r.render(1)
+        n += 1
+        assert r.renderProgress() == (n, spp)
+    assert n == spp and r.status() == abi.STATUS_READY | abi.STATUS_DONE
+    got = r.readbackAccumulator()
+    st = r.stats()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert 3 <= st.batches < spp, st.batches   # merged (48 one-sample batches would be the old behaviour)
+    # a caller slower than the GPU still gets one batch per call
+    _start(r, sc, w, h, 3, B, samples_in_flight=16)
+    for _ in range(3):
+        r.render(1)
+        r.wait()
+    assert r.stats().batches == 3
+
+
 def test_sample_sharding_is_the_same_sample_set(gpu_renderer):
     """§8e: renderers with disjoint first_sample ranges together trace exactly the samples of one big render."""
     sc = _scene("cornell_sphere")
