@@ -321,6 +321,67 @@ uint32_t emu_get_lights(void* h, pt_area_light* out, uint32_t cap) {
   return (uint32_t)e->hs.lights.size();
 }
 
+// ---- experiment (EMU_CULL_PROBE=1): how many node visits would a stack that also carries each entry's ENTRY DISTANCE save? --------
+// The product's stack holds child refs only: an entry pushed before a closer hit was found is still fetched and slab-tested when it
+// comes up.  With the entry distance beside the ref, a pop can drop it (tn > best.t) without touching the node.  The probe walks the
+// same tree with the same child arithmetic as trav_visit (scalar formulation: a node, then its leaf children at once) twice per ray,
+// with and without that test, and counts node fetches.  Harness-only; nothing here is compiled into libptamd.so.
+struct ProbeCounts { unsigned long long nodes = 0, nodes_cull = 0, tris = 0, tris_cull = 0, rays = 0, mismatch = 0; };
+static ProbeCounts g_probe;
+static RayHit probe_closest(const DeviceScene& S, vec3 o, vec3 d, float tmin, float tmax, bool cull, unsigned long long* nodes, unsigned long long* tris) {
+  RayHit best; best.t = tmax; best.u = best.v = 0; best.tri = kInvalidRef; best.gid = kInvalidRef;
+  if (S.root_ref == kInvalidRef) return best;
+  vec3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  if (!(fabsf(inv.x) <= 1e30f)) inv.x = copysignf(1e30f, d.x);
+  if (!(fabsf(inv.y) <= 1e30f)) inv.y = copysignf(1e30f, d.y);
+  if (!(fabsf(inv.z) <= 1e30f)) inv.z = copysignf(1e30f, d.z);
+  const bool gx = inv.x < 0, gy = inv.y < 0, gz = inv.z < 0;
+  auto test_tri = [&](uint32_t ti) {
+    (*tris)++;
+    const TriRec& tr = S.tris[ti];
+    float t, u, v;
+    if (!intersect_triangle(o, d, tmin, best.t, tr, &t, &u, &v)) return;
+    if (t < best.t || best.tri == kInvalidRef || tr.gid < best.gid) { best.t = t; best.u = u; best.v = v; best.tri = ti; best.gid = tr.gid; }
+  };
+  if (S.root_ref & kLeafBit) { test_tri(S.root_ref & ~kLeafBit); return best; }
+  std::vector<std::pair<uint32_t, float>> stack;
+  uint32_t cur = S.root_ref;
+  for (;;) {
+    const BvhNode n = S.nodes[cur];
+    (*nodes)++;
+    const float ax = node_scale(n.exp[0]) * inv.x, ay = node_scale(n.exp[1]) * inv.y, az = node_scale(n.exp[2]) * inv.z;
+    const float bx = (n.origin[0] - o.x) * inv.x, by = (n.origin[1] - o.y) * inv.y, bz = (n.origin[2] - o.z) * inv.z;
+    const uint32_t nx = gx ? n.qhi[0] : n.qlo[0], fx = gx ? n.qlo[0] : n.qhi[0];
+    const uint32_t ny = gy ? n.qhi[1] : n.qlo[1], fy = gy ? n.qlo[1] : n.qhi[1];
+    const uint32_t nz = gz ? n.qhi[2] : n.qlo[2], fz = gz ? n.qlo[2] : n.qhi[2];
+    std::pair<float, uint32_t> inner[4];
+    int ni = 0;
+    uint32_t leaves[4]; int nl = 0;
+    for (int k = 0; k < 4; k++) {
+      const float tnx = __builtin_fmaf((float)((nx >> (8 * k)) & 0xffu), ax, bx), tfx = __builtin_fmaf((float)((fx >> (8 * k)) & 0xffu), ax, bx);
+      const float tny = __builtin_fmaf((float)((ny >> (8 * k)) & 0xffu), ay, by), tfy = __builtin_fmaf((float)((fy >> (8 * k)) & 0xffu), ay, by);
+      const float tnz = __builtin_fmaf((float)((nz >> (8 * k)) & 0xffu), az, bz), tfz = __builtin_fmaf((float)((fz >> (8 * k)) & 0xffu), az, bz);
+      const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), tmin);
+      const float tf = fminf(fminf(fminf(tfx, tfy), tfz), best.t);
+      const bool hit = n.ref[k] != kInvalidRef && tn <= __builtin_fmaf(tf, 1.0000005f, 1e-30f);
+      if (!hit) continue;
+      if (n.ref[k] & kLeafBit) leaves[nl++] = n.ref[k] & ~kLeafBit; else inner[ni++] = {tn, n.ref[k]};
+    }
+    for (int k = 0; k < nl; k++) test_tri(leaves[k]);
+    std::stable_sort(inner, inner + ni, [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first < b.first; });
+    for (int k = ni - 1; k >= 1; k--) stack.push_back({inner[k].second, inner[k].first});
+    if (ni > 0) { cur = inner[0].second; continue; }
+    bool got = false;
+    while (!stack.empty()) {
+      const auto e = stack.back(); stack.pop_back();
+      // (the same conservative comparison the slab test uses: an entry is only dropped when its children could not pass it)
+      if (cull && !(e.second <= __builtin_fmaf(best.t, 1.0000005f, 1e-30f))) continue;
+      cur = e.first; got = true; break;
+    }
+    if (!got) return best;
+  }
+}
+
 // One sample of every pixel, following the kernel sequence of kernels.hip per path.
 void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32_t* hits /*B*W*H*2 or null*/) {
   Emu* e = (Emu*)h;
@@ -340,6 +401,12 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
         const float ir = S.has_alpha ? Halton{halton_table(S.halton), rg.offset, dim}.sample1d() : 0.0f;
         RayHit hit = traverse<false, true>(S, o, d, 1e-3f, kInf, ir, st, &tc);
         g_nodes += tc.nodes; g_tris += tc.tris; g_rays++;
+        if (getenv("EMU_CULL_PROBE") && !S.has_alpha) {
+          const RayHit a = probe_closest(S, o, d, 1e-3f, kInf, false, &g_probe.nodes, &g_probe.tris);
+          const RayHit c = probe_closest(S, o, d, 1e-3f, kInf, true, &g_probe.nodes_cull, &g_probe.tris_cull);
+          g_probe.rays++;
+          if (a.tri != hit.tri || c.tri != hit.tri || a.t != hit.t || c.t != hit.t) g_probe.mismatch++;
+        }
         if (hits && hit.tri != kInvalidRef) { hits[((size_t)b * NP + pid) * 2] = S.tris[hit.tri].inst; hits[((size_t)b * NP + pid) * 2 + 1] = S.tris[hit.tri].prim; }
         if (hit.tri == kInvalidRef) {
           if (S.env_texture >= 0) L = L + stage_miss(S, d, att, b, lastPdf, lastSpec);
@@ -377,6 +444,10 @@ void emu_trace_primary(void* h, uint32_t sample, pt_hit_record* out) {
       if (hit.tri != kInvalidRef) { r.t = hit.t; r.u = hit.u; r.v = hit.v; r.instance = S.tris[hit.tri].inst; r.primitive = S.tris[hit.tri].prim; }
       else { r.t = r.u = r.v = 0; r.instance = r.primitive = -1; }
     }
+}
+void emu_get_probe(unsigned long long out[6]) {
+  out[0] = g_probe.nodes; out[1] = g_probe.nodes_cull; out[2] = g_probe.tris; out[3] = g_probe.tris_cull; out[4] = g_probe.rays; out[5] = g_probe.mismatch;
+  g_probe = ProbeCounts{};
 }
 void emu_get_counts(unsigned long long out[3]) { out[0] = g_nodes; out[1] = g_tris; out[2] = g_rays; g_nodes = g_tris = g_rays = 0; }
 float emu_halton(void* h, uint32_t i, uint32_t d) { return halton(halton_table(((Emu*)h)->halton.data()), i, d); }
