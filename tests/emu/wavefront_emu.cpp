@@ -6,6 +6,7 @@
 //
 // The BVH used here is a throw-away host median-split builder that emits the product's BvhNode/TriRec layout.
 #include <algorithm>
+#include <functional>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -30,6 +31,11 @@ struct Emu {
   std::vector<BvhNode> nodes;
   DeviceScene S{};
   pt_render_params params{};
+  // experiment (EMU_WIDE_PROBE): N-wide trees collapsed from the same binary tree, one per width
+  struct WideNode { int count; Box3 box[8]; uint32_t ref[8]; };  // ref: kLeafBit | triangle (tris[] order) or index into wide[]
+  std::vector<WideNode> wide[9];
+  uint32_t wide_root[9] = {0};
+  std::vector<std::vector<uint32_t>> groups;  // multi-triangle leaves of the probe trees: ref = kLeafBit | 0x40000000 | group index
 };
 
 Box3 tri_box(const TriRec& t, const vec3& v1, const vec3& v2) {
@@ -223,6 +229,124 @@ void collapse(Emu& e, const std::vector<BinNode>& bin, const std::vector<uint32_
   for (int k = 0; k < count; k++) if (!(refs[k] & kLeafBit)) collapse(e, bin, order, boxes, refs[k]);
 }
 
+// ---- experiment (EMU_WIDE_PROBE=1): node visits per ray of N-wide trees (N = 4, 6, 8) under different child-ordering rules ------
+// The trees are collapsed from the SAME binary tree as the product's 4-wide one (open the internal child with the largest surface
+// area until N slots are used), child boxes inflated and quantised to 8 bits against the node's own box exactly like quantize_node4.
+// Ordering rules: 0 = all hit children sorted by entry distance (the product's rule), 1 = nearest first, the others in slot order,
+// 2 = slots visited in the order slot ^ octant, slots assigned at build time by the child's centroid octant inside the node (what an
+// octant-ordered wide BVH does, Ylitie et al. 2017).  Harness-only.
+static void quantize_boxes(const Box3* in, int n, Box3* out) {
+  float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+  for (int k = 0; k < n; k++) for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], in[k].lo[a]); hi[a] = fmaxf(hi[a], in[k].hi[a]); }
+  for (int a = 0; a < 3; a++) {
+    const float need = (hi[a] - lo[a]) * (1.0f / 255.0f);
+    uint32_t e = (f2u(need) >> 23) & 0xffu;
+    if ((f2u(need) & 0x7fffffu) != 0) e += 1;
+    if (e < 1) e = 1; if (e > 254) e = 254;
+    while (e < 254 && lo[a] + 255.0f * node_scale((uint8_t)e) < hi[a]) e += 1;
+    const float sc = node_scale((uint8_t)e), inv = 1.0f / sc;
+    for (int k = 0; k < n; k++) {
+      int ql = (int)floorf((in[k].lo[a] - lo[a]) * inv); ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+      while (ql > 0 && lo[a] + (float)ql * sc > in[k].lo[a]) ql--;
+      int qh = (int)ceilf((in[k].hi[a] - lo[a]) * inv); qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+      while (qh < 255 && lo[a] + (float)qh * sc < in[k].hi[a]) qh++;
+      out[k].lo[a] = lo[a] + (float)ql * sc; out[k].hi[a] = lo[a] + (float)qh * sc;
+    }
+  }
+}
+static int g_leaf_max = 1;                       // triangles per leaf of the tree being collapsed
+static std::vector<uint32_t> g_subtree_leaves;   // per binary node: triangles below it
+static void gather_leaves(const std::vector<BinNode>& bin, uint32_t ref, std::vector<uint32_t>& out) {
+  if (ref & kLeafBit) { out.push_back(ref & ~kLeafBit); return; }
+  gather_leaves(bin, bin[ref].left, out); gather_leaves(bin, bin[ref].right, out);
+}
+static uint32_t collapse_wide(Emu& e, int store, int N, const std::vector<BinNode>& bin, const std::vector<uint32_t>& order, const std::vector<Box3>& boxes, uint32_t i, bool octant_slots) {
+  uint32_t refs[8] = {bin[i].left, bin[i].right}; int count = 2;
+  auto box_of = [&](uint32_t ref) { return (ref & kLeafBit) ? boxes[order[ref & ~kLeafBit]] : bin[ref].box; };
+  auto closed = [&](uint32_t ref) { return (ref & kLeafBit) || (int)g_subtree_leaves[ref] <= g_leaf_max; };  // stays one child slot
+  while (count < N) {
+    int best = -1; float ba = -1.0f;
+    for (int k = 0; k < count; k++) if (!closed(refs[k])) { const float a = half_area(box_of(refs[k])); if (a > ba) { ba = a; best = k; } }
+    if (best < 0) break;
+    const uint32_t r = refs[best];
+    refs[best] = bin[r].left; refs[count++] = bin[r].right;
+  }
+  Box3 bx[8], q[8];
+  for (int k = 0; k < count; k++) bx[k] = inflate_box(box_of(refs[k]));
+  quantize_boxes(bx, count, q);
+  const uint32_t me = (uint32_t)e.wide[store].size();
+  e.wide[store].push_back({});
+  Emu::WideNode w; w.count = N;
+  for (int k = 0; k < 8; k++) w.ref[k] = kInvalidRef;
+  int slot_of[8];
+  if (octant_slots && N == 8) {
+    // greedy: children take the free slot closest (Hamming) to the octant of their centroid relative to the node's centre
+    float c[3]; Box3 nb = bin[i].box;
+    for (int a = 0; a < 3; a++) c[a] = 0.5f * (nb.lo[a] + nb.hi[a]);
+    bool used[8] = {false};
+    for (int k = 0; k < count; k++) {
+      int o = 0;
+      for (int a = 0; a < 3; a++) if (0.5f * (bx[k].lo[a] + bx[k].hi[a]) > c[a]) o |= 1 << a;
+      int bestslot = -1, bd = 99;
+      for (int sl = 0; sl < 8; sl++) if (!used[sl]) { const int d = __builtin_popcount(sl ^ o); if (d < bd) { bd = d; bestslot = sl; } }
+      used[bestslot] = true; slot_of[k] = bestslot;
+    }
+  } else for (int k = 0; k < count; k++) slot_of[k] = k;
+  for (int k = 0; k < count; k++) { w.box[slot_of[k]] = q[k]; w.ref[slot_of[k]] = (refs[k] & kLeafBit) ? refs[k] : 0u; }
+  for (int k = 0; k < count; k++) {
+    if (refs[k] & kLeafBit) continue;
+    if (closed(refs[k])) {  // a multi-triangle leaf
+      e.groups.push_back({});
+      gather_leaves(bin, refs[k], e.groups.back());
+      w.ref[slot_of[k]] = kLeafBit | 0x40000000u | (uint32_t)(e.groups.size() - 1);
+    } else w.ref[slot_of[k]] = collapse_wide(e, store, N, bin, order, boxes, refs[k], octant_slots);
+  }
+  e.wide[store][me] = w;
+  return me;
+}
+struct WideCounts { unsigned long long nodes[9][3] = {{0}}, tris[9][3] = {{0}}, rays = 0, mismatch = 0; };
+static WideCounts g_wide;
+static RayHit wide_closest(const Emu& e, int store, int rule, vec3 o, vec3 d, float tmin, float tmax, unsigned long long* nodes, unsigned long long* tris) {
+  const DeviceScene& S = e.S;
+  RayHit best; best.t = tmax; best.u = best.v = 0; best.tri = kInvalidRef; best.gid = kInvalidRef;
+  vec3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  if (!(fabsf(inv.x) <= 1e30f)) inv.x = copysignf(1e30f, d.x);
+  if (!(fabsf(inv.y) <= 1e30f)) inv.y = copysignf(1e30f, d.y);
+  if (!(fabsf(inv.z) <= 1e30f)) inv.z = copysignf(1e30f, d.z);
+  const int oct = (inv.x < 0 ? 1 : 0) | (inv.y < 0 ? 2 : 0) | (inv.z < 0 ? 4 : 0);
+  std::vector<uint32_t> stack;
+  uint32_t cur = e.wide_root[store];
+  for (;;) {
+    const Emu::WideNode& n = e.wide[store][cur];
+    (*nodes)++;
+    std::pair<float, uint32_t> inner[8]; int ni = 0;
+    for (int j = 0; j < 8; j++) {
+      const int k = rule == 2 ? (j ^ oct) : j;   // rule 2: a ray going +x visits the low-x slots first
+      if (n.ref[k] == kInvalidRef) continue;
+      const float tn = slab_entry(n.box[k].lo, n.box[k].hi, o, inv, tmin, best.t);
+      if (tn < 0.0f) continue;
+      if (n.ref[k] & kLeafBit) {
+        static const std::vector<uint32_t> one(1, 0u);
+        const bool grp = (n.ref[k] & 0x40000000u) != 0;
+        const std::vector<uint32_t>& list = grp ? e.groups[n.ref[k] & 0x3fffffffu] : one;
+        for (size_t g = 0; g < list.size(); g++) {
+          (*tris)++;
+          const uint32_t ti = grp ? list[g] : (n.ref[k] & ~kLeafBit);
+          const TriRec& tr = S.tris[ti];
+          float t, u, v;
+          if (intersect_triangle(o, d, tmin, best.t, tr, &t, &u, &v) && (t < best.t || best.tri == kInvalidRef || tr.gid < best.gid)) { best.t = t; best.u = u; best.v = v; best.tri = ti; best.gid = tr.gid; }
+        }
+      } else inner[ni++] = {tn, n.ref[k]};
+    }
+    if (rule == 0) std::stable_sort(inner, inner + ni, [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first < b.first; });
+    else if (rule == 1 && ni > 1) { int m = 0; for (int k = 1; k < ni; k++) if (inner[k].first < inner[m].first) m = k; std::swap(inner[0], inner[m]); }
+    for (int k = ni - 1; k >= 1; k--) stack.push_back(inner[k].second);
+    if (ni > 0) { cur = inner[0].second; continue; }
+    if (stack.empty()) return best;
+    cur = stack.back(); stack.pop_back();
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -285,6 +409,22 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
     if (!(root & kLeafBit)) {
       e->nodes.assign(bin.size(), BvhNode{});
       if (getenv("EMU_SAH_COLLAPSE")) collapse_sah(*e, bin, order, boxes, root); else collapse(*e, bin, order, boxes, root);
+      if (getenv("EMU_WIDE_PROBE")) {
+        g_subtree_leaves.assign(bin.size(), 0);
+        {
+          std::function<uint32_t(uint32_t)> count_leaves = [&](uint32_t ref) -> uint32_t {
+            if (ref & kLeafBit) return 1u;
+            return g_subtree_leaves[ref] = count_leaves(bin[ref].left) + count_leaves(bin[ref].right);
+          };
+          count_leaves(root);
+        }
+        g_leaf_max = 1;
+        for (int N : {4, 6, 8}) e->wide_root[N] = collapse_wide(*e, N, N, bin, order, boxes, root, false);
+        e->wide_root[0] = collapse_wide(*e, 0, 8, bin, order, boxes, root, true);   // store 0: the 8-wide tree with octant-assigned slots
+        // stores 1, 2, 3: 4-wide trees whose leaves hold up to 2, 3, 4 triangles (every binary subtree that small is one leaf)
+        for (int M = 2; M <= 4; M++) { g_leaf_max = M; e->wide_root[M - 1] = collapse_wide(*e, M - 1, 4, bin, order, boxes, root, false); }
+        g_leaf_max = 1;
+      }
     }
   }
   e->tris.resize(tmp.size());
@@ -401,6 +541,19 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
         const float ir = S.has_alpha ? Halton{halton_table(S.halton), rg.offset, dim}.sample1d() : 0.0f;
         RayHit hit = traverse<false, true>(S, o, d, 1e-3f, kInf, ir, st, &tc);
         g_nodes += tc.nodes; g_tris += tc.tris; g_rays++;
+        if (!e->wide[8].empty() && !S.has_alpha) {
+          for (int N : {4, 6, 8})
+            for (int rule = 0; rule < 3; rule++) {
+              if (rule == 2 && N != 8) continue;
+              const RayHit w = wide_closest(*e, rule == 2 ? 0 : N, rule, o, d, 1e-3f, kInf, &g_wide.nodes[N][rule], &g_wide.tris[N][rule]);
+              if (w.tri != hit.tri || w.t != hit.t) g_wide.mismatch++;
+            }
+          for (int M = 2; M <= 4; M++) {  // 4-wide, leaves of up to M triangles (counts kept in the unused slots [M - 1][0])
+            const RayHit w = wide_closest(*e, M - 1, 0, o, d, 1e-3f, kInf, &g_wide.nodes[M - 1][0], &g_wide.tris[M - 1][0]);
+            if (w.tri != hit.tri || w.t != hit.t) g_wide.mismatch++;
+          }
+          g_wide.rays++;
+        }
         if (getenv("EMU_CULL_PROBE") && !S.has_alpha) {
           const RayHit a = probe_closest(S, o, d, 1e-3f, kInf, false, &g_probe.nodes, &g_probe.tris);
           const RayHit c = probe_closest(S, o, d, 1e-3f, kInf, true, &g_probe.nodes_cull, &g_probe.tris_cull);
@@ -444,6 +597,14 @@ void emu_trace_primary(void* h, uint32_t sample, pt_hit_record* out) {
       if (hit.tri != kInvalidRef) { r.t = hit.t; r.u = hit.u; r.v = hit.v; r.instance = S.tris[hit.tri].inst; r.primitive = S.tris[hit.tri].prim; }
       else { r.t = r.u = r.v = 0; r.instance = r.primitive = -1; }
     }
+}
+void emu_get_wide(double out[26]) {
+  int i = 0;
+  const double r = g_wide.rays ? (double)g_wide.rays : 1.0;
+  for (int N : {4, 6, 8}) for (int rule = 0; rule < 3; rule++) { out[i++] = g_wide.nodes[N][rule] / r; out[i++] = g_wide.tris[N][rule] / r; }
+  for (int M = 2; M <= 4; M++) { out[i++] = g_wide.nodes[M - 1][0] / r; out[i++] = g_wide.tris[M - 1][0] / r; }
+  out[24] = (double)g_wide.rays; out[25] = (double)g_wide.mismatch;
+  g_wide = WideCounts{};
 }
 void emu_get_probe(unsigned long long out[6]) {
   out[0] = g_probe.nodes; out[1] = g_probe.nodes_cull; out[2] = g_probe.tris; out[3] = g_probe.tris_cull; out[4] = g_probe.rays; out[5] = g_probe.mismatch;
