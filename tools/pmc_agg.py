@@ -3,7 +3,7 @@
 import csv, glob, sys
 from collections import defaultdict
 def short(name):
-    for k in ("k_trace_closest<false, false>", "k_trace_shadow<false, false>", "k_trace_closest<false, true>", "k_trace_shadow<false, true>",
+    for k in ("k_trace_closest<false, false>", "k_trace_shadow<false, false>", "k_trace_closest<false, true>", "k_trace_shadow<false, true>", "k_trace_closest<(bool)0, (bool)0>", "k_trace_closest<(bool)0, (bool)1>", "k_trace_shadow<(bool)0, (bool)0>", "k_trace_shadow<(bool)0, (bool)1>",
               "k_shade", "k_raygen", "k_accumulate"):
         if k in name: return k
     return None
