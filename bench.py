@@ -200,6 +200,7 @@ def kernel_block(name, items, item_name, ms, launches, alg_bytes_per_item, pmc, 
 
 def main():
     args = parse_args()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL / cross-process tensor sharing need on this pool
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.inproc:
         sys.exit(self_launch(args))
 

@@ -495,6 +495,16 @@ int dev_wait(pt_renderer* r) {
   if (r->started) { const int rc = flush_pending(r, true); if (rc != PT_OK) return rc; }
   PT_HIP(hipStreamSynchronize(r->stream));
   collect_timings(r);
+  if (r->started && getenv("PTAMD_DUMP_CHUNKS")) {  // analysis aid: 64-ray chunks per bounce of the LAST batch (the counters are per batch)
+    BatchCounters h{};
+    if (hipMemcpy(&h, r->ctr.p, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+      fprintf(stderr, "ptamd chunks closest:");
+      for (uint32_t b = 0; b < r->S.max_bounces; b++) fprintf(stderr, " %u", h.chunks_closest[b]);
+      fprintf(stderr, "\nptamd chunks shadow:");
+      for (uint32_t b = 0; b < r->S.max_bounces; b++) fprintf(stderr, " %u", h.chunks_shadow[b]);
+      fprintf(stderr, "\n");
+    }
+  }
   if (r->started)
     r->timer_ms = (uint64_t)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r->render_start).count();
   return PT_OK;

@@ -4,9 +4,9 @@
 #   2. --pmc FETCH_SIZE, 3. --pmc WRITE_SIZE, 4. --pmc SQ instruction counters, 5. --pmc L1 / L2 request counters: separate passes of `bench.py --pmc-pass`
 #      (full-size batches only), never combined with trace domains (MI355X_MICROARCH.md §HBM / §rocprofv3 PMC slots)
 # then tools/summarize_prof.py (newest output of each pass) writes profiles/<tag>_<wl>_{summary.md,kernel_stats.csv} and
-# profiles/r02_pmc_<wl>.json.
+# profiles/<round>_pmc_<wl>.json.
 set -u
-WL=$1; TAG=${2:-r02}; OUT=gpurun_out/prof; mkdir -p $OUT
+WL=$1; TAG=${2:-r03}; OUT=gpurun_out/prof; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${WL}_trace -- python3 bench.py --workload $WL --no-cpu-baseline > $OUT/${WL}_bench_under_rocprof.json 2> $OUT/${WL}_trace.err || echo "trace pass failed"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${WL}_fetch -- python3 bench.py --workload $WL --pmc-pass --steps 2 > $OUT/${WL}_fetch.json 2> $OUT/${WL}_fetch.err || echo "fetch pass failed"
