@@ -45,8 +45,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 L2_PEAK_GBS = 34500.0       # aggregate over the 8 XCD L2s
 VALU_PEAK_TLOPS = 78.6432   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz, in 1e12 lane-ops/s
-L2_REQ_PEAK_G = 80.9        # random 64-byte read requests served per second to lane-private gathers (profiles/r02_calib_gather.md; r03: see r03_calib_gather.md)
-L1_TAG_PEAK_G = 256 * 2.1   # vector-L1 tag lookups per second: one per clock per CU at the ~2.1 GHz the trace kernels hold (profiles/r03_calib_gather.md)
+# Measured request ceilings (profiles/r03_calib_gather.md; tools/calib_gather2.hip):
+L2_HIT_REQ_PEAK_G = 250.0   # L2 read requests served per second when every request hits (2 MiB table, one dwordx4 per lane)
+L2_MISS_REQ_PEAK_G = 55.0   # requests per second on the L2-miss path (Infinity Cache / HBM), any size up to 128 B, 2..16 in flight per lane
+L1_TAG_PEAK_G = 833.0       # vector-L1 tag lookups per second: lane-private 64-byte records from an L2-resident table = 166.6 G records/s x 5
+                            # lookups each (1.55 per clock per CU at 2.1 GHz); lane-private 128-byte records hold 0.98 per clock per CU
 HBM_TARGET_FRAC = 0.40      # north_star: ">= 40 % of HBM peak on the traversal kernel"
 
 WORKLOADS = {
@@ -177,8 +180,13 @@ def kernel_block(name, items, item_name, ms, launches, alg_bytes_per_item, pmc, 
                                         "peak_G_per_s": L1_TAG_PEAK_G, "frac": round(tg / L1_TAG_PEAK_G, 4)}
         if k.get("l2_read_requests_per_item") is not None:
             rq = items * k["l2_read_requests_per_item"] / sec / 1e9 if sec > 0 else 0.0
+            hr = k.get("l2_hit_rate")
+            hr = 0.0 if hr is None else hr
+            # hits and misses have separate measured ceilings; the fraction of the request path in use is their sum
+            f = rq * hr / L2_HIT_REQ_PEAK_G + rq * (1.0 - hr) / L2_MISS_REQ_PEAK_G
             secondary["l2_request_rate"] = {"requests_per_%s" % unit_item: round(k["l2_read_requests_per_item"], 2), "achieved_Greq_per_s": round(rq, 2),
-                                            "peak_Greq_per_s": L2_REQ_PEAK_G, "frac": round(rq / L2_REQ_PEAK_G, 4), "l2_hit_rate": k.get("l2_hit_rate")}
+                                            "l2_hit_rate": round(hr, 4), "hit_Greq_per_s": round(rq * hr, 2), "hit_peak_Greq_per_s": L2_HIT_REQ_PEAK_G,
+                                            "miss_Greq_per_s": round(rq * (1.0 - hr), 2), "miss_peak_Greq_per_s": L2_MISS_REQ_PEAK_G, "frac": round(f, 4)}
     counter_based = achieved is not None
     if not counter_based:  # no committed counter pass for this workload: the algorithmic figure, labelled as such
         achieved = alg
