@@ -6,7 +6,7 @@
 One "step" = one pass of the hot path over one batch: S samples per pixel of the whole frame (raygen ->
 {closest-hit, shade/BSDF/NEE, shadow} x bounces -> accumulate).  Default workload: C3 (BASELINE.json configs[2]: the
 1.04 M-triangle instanced field, 1920x1080, 8 bounces — the largest single-GPU configuration and the one the
-north-star targets are written on), S = 64, K = 8, W = 2.  `--workload c2` = configs[1].
+north-star targets are written on), S = the library's own batch size for the image (128 at 1080p), K = 4, W = 2.  `--workload c2` = configs[1].
 Metric: Msamples/s = W*H*spp*B / t / 1e6, B = configured max bounces.
 
 N > 1: one process per GPU.  Either launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
@@ -77,10 +77,12 @@ ALGORITHMIC_BYTES_SHADE = 368.0 + 64.0 + 64.0 + 112.0 + 48.0 + 48.0
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--spp-per-step", type=int, default=0,
+                    help="samples per pixel of one step = one batch (samples in flight); 0 = what the library would choose for this image "
+                         "(pt_plan_queues: 128 at 1920x1080 on an empty MI355X, 42 at 3840x2160)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline sample")
@@ -240,6 +242,12 @@ def main():
 
     factory, W, H, full_spp, B = scenes.CONFIGS[args.workload]
     S, K = args.spp_per_step, args.steps
+    if S <= 0:
+        import ctypes as _C
+        plan = abi.QueuePlan()
+        free_b, _tot = torch.cuda.mem_get_info(local_rank)
+        abi.check(abi.load_library(), abi.load_library().pt_plan_queues(W, H, 1 << 20, 0, int(free_b), 0, 4, _C.byref(plan)))
+        S = int(plan.samples_in_flight)
     ndev_all = args.gpus if (args.inproc and args.gpus > 1) else world
     strong_spp = 0
     if args.strong:

@@ -598,6 +598,87 @@ void emu_trace_primary(void* h, uint32_t sample, pt_hit_record* out) {
       else { r.t = r.u = r.v = 0; r.instance = r.primitive = -1; }
     }
 }
+// ---- experiment (emu_packet_probe): camera rays of one 8x8 pixel tile traced as ONE packet (a wave that walks the tree once for its 64
+// rays: a node is visited when any ray's slab test passes with that ray's current best t; children ordered by the smallest entry
+// distance among the rays that hit them; a leaf's triangle is tested by every ray whose slab test passed).  Counts node visits and
+// triangle rounds per PACKET against the per-ray traversal's totals over the same 64 rays.  out: {packets, packet node visits, packet
+// triangle rounds, per-ray node visits (sum), per-ray triangle tests (sum), mismatching hits}
+void emu_packet_probe(void* h, uint32_t sample, double out[6]) {
+  Emu* e = (Emu*)h;
+  const DeviceScene& S = e->S;
+  std::vector<uint32_t> lds(kLdsStack + 1), spill(kSpillStack), pend(kPendLeaves + 1);
+  double packets = 0, pn = 0, pt_ = 0, rn = 0, rt = 0, mism = 0;
+  for (uint32_t ty = 0; ty < (S.height + 7) / 8; ty++)
+    for (uint32_t tx = 0; tx < (S.width + 7) / 8; tx++) {
+      struct R { vec3 o, d, inv; RayHit best; bool on; } r[64];
+      int n = 0;
+      for (uint32_t l = 0; l < 64; l++) {
+        const uint32_t x = tx * 8 + (l & 7), y = ty * 8 + (l >> 3);
+        if (x >= S.width || y >= S.height) continue;
+        const RayGenOut rg = stage_raygen(S, x, y, sample);
+        R& q = r[n++];
+        q.o = rg.o; q.d = rg.d; q.inv = v3(1.0f / rg.d.x, 1.0f / rg.d.y, 1.0f / rg.d.z); q.on = true;
+        q.best.t = kInf; q.best.u = q.best.v = 0; q.best.tri = kInvalidRef; q.best.gid = kInvalidRef;
+        TraversalStack st; st.lds = lds.data(); st.pend = pend.data(); st.lds_stride = 1; st.spill = spill.data(); st.spill_stride = 1;
+        TraversalCount tc;
+        const RayHit ref = traverse<false, true>(S, rg.o, rg.d, 1e-3f, kInf, 0.0f, st, &tc);
+        rn += tc.nodes; rt += tc.tris;
+        q.best.gid = ref.tri;  // (stash the per-ray answer for the comparison below)
+      }
+      if (n == 0 || S.root_ref == kInvalidRef || (S.root_ref & kLeafBit)) continue;
+      uint32_t want[64];
+      for (int k = 0; k < n; k++) { want[k] = r[k].best.gid; r[k].best.gid = kInvalidRef; }
+      packets++;
+      std::vector<uint32_t> stack;
+      uint32_t cur = S.root_ref;
+      for (;;) {
+        const BvhNode nd = S.nodes[cur];
+        pn++;
+        float tmin_child[4] = {kInf, kInf, kInf, kInf};
+        bool any[4] = {false, false, false, false};
+        bool hitk[64][4];
+        for (int k = 0; k < n; k++) {
+          const R& q = r[k];
+          for (int c = 0; c < 4; c++) {
+            hitk[k][c] = false;
+            if (nd.ref[c] == kInvalidRef) continue;
+            float lo[3], hi[3];
+            for (int a = 0; a < 3; a++) {
+              lo[a] = nd.origin[a] + (float)((nd.qlo[a] >> (8 * c)) & 0xffu) * node_scale(nd.exp[a]);
+              hi[a] = nd.origin[a] + (float)((nd.qhi[a] >> (8 * c)) & 0xffu) * node_scale(nd.exp[a]);
+            }
+            const float tn = slab_entry(lo, hi, q.o, q.inv, 1e-3f, q.best.t);
+            if (tn < 0.0f) continue;
+            hitk[k][c] = true; any[c] = true; tmin_child[c] = fminf(tmin_child[c], tn);
+          }
+        }
+        // leaves: one triangle round per hit leaf child (all rays whose slab test passed take part)
+        for (int c = 0; c < 4; c++) {
+          if (!any[c] || !(nd.ref[c] & kLeafBit)) continue;
+          pt_++;
+          const uint32_t ti = nd.ref[c] & ~kLeafBit;
+          const TriRec& tr = S.tris[ti];
+          for (int k = 0; k < n; k++) {
+            if (!hitk[k][c]) continue;
+            R& q = r[k];
+            float t, u, v;
+            if (intersect_triangle(q.o, q.d, 1e-3f, q.best.t, tr, &t, &u, &v) && (t < q.best.t || q.best.tri == kInvalidRef || tr.gid < q.best.gid)) {
+              q.best.t = t; q.best.u = u; q.best.v = v; q.best.tri = ti; q.best.gid = tr.gid;
+            }
+          }
+        }
+        std::pair<float, uint32_t> inner[4]; int ni = 0;
+        for (int c = 0; c < 4; c++) if (any[c] && !(nd.ref[c] & kLeafBit)) inner[ni++] = {tmin_child[c], nd.ref[c]};
+        std::stable_sort(inner, inner + ni, [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first < b.first; });
+        for (int k = ni - 1; k >= 1; k--) stack.push_back(inner[k].second);
+        if (ni > 0) { cur = inner[0].second; continue; }
+        if (stack.empty()) break;
+        cur = stack.back(); stack.pop_back();
+      }
+      for (int k = 0; k < n; k++) if (r[k].best.tri != want[k]) mism++;
+    }
+  out[0] = packets; out[1] = pn; out[2] = pt_; out[3] = rn; out[4] = rt; out[5] = mism;
+}
 void emu_get_wide(double out[26]) {
   int i = 0;
   const double r = g_wide.rays ? (double)g_wide.rays : 1.0;
