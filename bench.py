@@ -82,7 +82,7 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--spp-per-step", type=int, default=0,
                     help="samples per pixel of one step = one batch (samples in flight); 0 = what the library would choose for this image "
-                         "(pt_plan_queues: 128 at 1920x1080 on an empty MI355X, 42 at 3840x2160)")
+                         "(pt_plan_queues: 128 at 1920x1080 on an empty MI355X, 45 at 3840x2160)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline sample")
