@@ -240,6 +240,10 @@ int pt_group_partition(uint32_t spp, uint32_t members, int32_t flags, uint32_t g
  * (ncclCommInitAll, ncclCommDestroy, ncclAllReduce, ncclGroupStart, ncclGroupEnd, ncclGetErrorString).  No GPU is touched:
  * a build-box check that the multi-GPU path can find its collective library.  PT_OK or PT_ERR_UNSUPPORTED (pt_last_error). */
 int pt_rccl_probe(void);
+/* The same on a GPU, one step further: a communicator of ONE rank on `device_ordinal`, the merge's grouped in-place
+ * ncclAllReduce(sum, float32) on a known pattern, result checked, communicator destroyed — every RCCL call the distinct-device merge
+ * makes, with its argument types and stream ordering, as far as a one-GPU box can run them. */
+int pt_rccl_selftest(int32_t device_ordinal);
 /* Renderer::~Renderer (renderer_pt.hpp:34) */
 void pt_destroy(pt_renderer* r);
 

@@ -195,6 +195,7 @@ SYMBOLS = [
     ("pt_group_partition", C.c_int, [C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("pt_rccl_probe", C.c_int, []),
+    ("pt_rccl_selftest", C.c_int, [C.c_int32]),
     ("pt_plan_queues", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(QueuePlan)]),
     ("pt_destroy", None, [C.c_void_p]),
     ("pt_start_render", C.c_int, [C.c_void_p, C.POINTER(SceneSnapshot), C.POINTER(RenderParams)]),

@@ -477,6 +477,44 @@ int pt_rccl_probe(void) {
   return PT_OK;
 }
 
+// The merge's RCCL calls on ONE device: communicator of one rank, a grouped in-place all-reduce(sum, f32) of a known pattern, result
+// checked, communicator destroyed.  What a one-GPU box can show of the distinct-device path (the calls, their argument types and
+// enumerators, stream ordering); the exchange over xGMI itself needs two GPUs.
+int pt_rccl_selftest(int32_t device_ordinal) {
+  std::lock_guard<std::mutex> l(g_rccl_mutex);
+  std::string why;
+  if (!g_rccl.load(&why)) return fail(PT_ERR_UNSUPPORTED, why);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_ordinal < 0 || device_ordinal >= ndev) return fail(PT_ERR_NO_DEVICE, "pt_rccl_selftest: no such HIP device");
+  PT_HIP(hipSetDevice(device_ordinal));
+  const size_t n = 4 * 1920 * 8;  // a few rows of a 1080p accumulator
+  std::vector<float> h(n);
+  for (size_t i = 0; i < n; i++) h[i] = (float)(i % 977) * 0.25f;
+  float* d = nullptr;
+  hipStream_t s = nullptr;
+  Rccl::comm_t comm = nullptr;
+  int rc = PT_OK;
+  do {
+    if (hipMalloc((void**)&d, n * sizeof(float)) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { rc = fail(PT_ERR_HIP, "pt_rccl_selftest: allocation failed"); break; }
+    if (hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(PT_ERR_HIP, "pt_rccl_selftest: upload failed"); break; }
+    const int dev = device_ordinal;
+    ncclResult_t e = g_rccl.CommInitAll(&comm, 1, &dev);
+    if (e != ncclSuccess) { rc = fail(PT_ERR_HIP, std::string("ncclCommInitAll failed: ") + g_rccl.GetErrorString(e)); break; }
+    e = g_rccl.GroupStart();
+    if (e == ncclSuccess) e = g_rccl.AllReduce(d, d, n, Rccl::kFloat32, Rccl::kSum, comm, s);
+    const ncclResult_t e2 = g_rccl.GroupEnd();
+    if (e != ncclSuccess || e2 != ncclSuccess) { rc = fail(PT_ERR_HIP, std::string("ncclAllReduce failed: ") + g_rccl.GetErrorString(e != ncclSuccess ? e : e2)); break; }
+    if (hipStreamSynchronize(s) != hipSuccess) { rc = fail(PT_ERR_HIP, "pt_rccl_selftest: stream synchronisation failed"); break; }
+    std::vector<float> back(n);
+    if (hipMemcpy(back.data(), d, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(PT_ERR_HIP, "pt_rccl_selftest: readback failed"); break; }
+    for (size_t i = 0; i < n; i++) if (back[i] != h[i]) { rc = fail(PT_ERR_HIP, "pt_rccl_selftest: a one-rank sum changed the data"); break; }
+  } while (0);
+  if (comm) (void)g_rccl.CommDestroy(comm);
+  if (s) (void)hipStreamDestroy(s);
+  if (d) (void)hipFree(d);
+  return rc;
+}
+
 int pt_create(const pt_create_info* info, pt_renderer** out) {
   if (!info || !out) return fail(PT_ERR_INVALID_ARGUMENT, "pt_create: null argument");
   *out = nullptr;

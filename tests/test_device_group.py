@@ -200,6 +200,55 @@ def test_gmon_with_fewer_buckets_than_members_presents_on_the_first_device(bucke
 
 
 @pytest.mark.gpu
+def test_rccl_calls_of_the_merge_run_on_one_device():
+    """The distinct-device merge (ncclCommInitAll, grouped ncclAllReduce(sum, f32) in place on the member's stream, ncclCommDestroy) has
+    never met hardware with two GPUs; with ONE rank every one of its calls still runs for real."""
+    lib = abi.load_library()
+    rc = lib.pt_rccl_selftest(0)
+    assert rc == 0, lib.pt_last_error()
+    # ... and a renderer created afterwards still works (RCCL's own streams / allocations do not disturb it)
+    r = Renderer(device=0)
+    try:
+        r.startRender(scenes.cornell_scene("bench"), (W, H), 2, max_bounces=B)
+        r.render(0)
+        assert np.isfinite(r.readbackAccumulator()).all()
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
+def test_torch_distributed_nccl_backend_reduces_the_accumulator_with_one_rank():
+    """bench.py's N > 1 path in miniature: process group on the `nccl` backend (= RCCL on ROCm), the library renders into a torch tensor,
+    sharding.reduce_accumulator all-reduces it.  One rank: the reduction must leave the image as it is."""
+    torch = pytest.importorskip("torch")
+    import torch.distributed as dist
+    from platinum_amd.sharding import reduce_accumulator
+    import os, socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+        r = Renderer(device=0)
+        try:
+            r.startRender(scenes.cornell_scene("bench"), (W, H), 3, max_bounces=B, external_accumulator=acc.data_ptr())
+            r.render(0)
+            r.wait()
+            before = acc.clone()
+            # world = 1 short-circuits in reduce_accumulator; call the collective itself, as world > 1 would
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+            assert torch.equal(acc, before) and float(acc[..., :3].max()) > 0
+            assert reduce_accumulator(acc, 1, dist) is acc
+        finally:
+            r.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
 def test_group_argument_errors():
     lib = abi.load_library()
     info = abi.CreateInfo()
