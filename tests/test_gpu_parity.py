@@ -158,6 +158,38 @@ def test_one_sample_render_calls_are_merged_into_batches_and_give_the_same_image
     assert r.stats().batches == 3
 
 
+def test_merged_render_calls_with_gmon_resolve_like_one_step(gpu_renderer):
+    """The merged batches of a render(1) loop cross GMoN bucket boundaries wherever they happen to fall; buckets and the resolved image
+    must not depend on it (the reference resolves after every frame: only the state after the last one is observable)."""
+    sc = _scene("cornell_sphere")
+    w, h, spp, B, buckets = 160, 96, 30, 5, 15
+    flags = abi.FLAG_MULTISCATTER_GGX | abi.FLAG_GMON
+    r = gpu_renderer
+    r.startRender(sc, (w, h), spp, gmonBuckets=buckets, flags=flags, max_bounces=B, samples_in_flight=8)
+    r.render(0)
+    ref = r.readbackAccumulator()
+    ref_b = [r.readGmonBucket(b) for b in range(buckets)]
+    r.startRender(sc, (w, h), spp, gmonBuckets=buckets, flags=flags, max_bounces=B, samples_in_flight=8)
+    while r.status() & abi.STATUS_BUSY:
+        r.render(1)
+    got = r.readbackAccumulator()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    for b in range(buckets):
+        assert r.readGmonBucket(b).tobytes() == ref_b[b].tobytes(), b
+    # a progressive read in the middle of the loop shows every accepted sample (presenting / reading flushes what is pending)
+    r.startRender(sc, (w, h), spp, gmonBuckets=buckets, flags=flags, max_bounces=B, samples_in_flight=8)
+    for _ in range(11):
+        r.render(1)
+    mid = r.readbackAccumulator()
+    assert r.renderProgress() == (11, spp)
+    # (11 samples touch 6 buckets: an EVEN count, for which the reference's resolve divides 0 by 0 on all-black pixels — G = NaN,
+    #  min(NaN, cap) = cap, c = n / 2, gmon.metal:44-53 — reproduced as is: the images must agree bit for bit, NaNs included)
+    assert np.isnan(mid[..., 0]).any() and np.isfinite(mid[..., 0]).any()
+    r.startRender(sc, (w, h), spp, gmonBuckets=buckets, flags=flags, max_bounces=B, samples_in_flight=8)
+    r.render(11)
+    assert np.array_equal(r.readbackAccumulator().view(np.uint32), mid.view(np.uint32))
+
+
 def test_sample_sharding_is_the_same_sample_set(gpu_renderer):
     """§8e: renderers with disjoint first_sample ranges together trace exactly the samples of one big render."""
     sc = _scene("cornell_sphere")
