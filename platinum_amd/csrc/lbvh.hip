@@ -383,23 +383,43 @@ __global__ void __launch_bounds__(256) k_ploc_apply(uint32_t n, const uint32_t* 
 
 #define LB_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = e_; goto done; } } while (0)
 
+// One device allocation per tree build, carved up front: the builder used to make ~30 hipMalloc / hipFree pairs per build (each a
+// driver round trip, every hipFree a device synchronisation) around 2.5 ms of kernels.
+struct Arena {
+  char* base = nullptr;
+  size_t off = 0, cap = 0;
+  static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
+  template <class T> T* take(size_t count) {
+    T* p = reinterpret_cast<T*>(base + off);
+    off += pad(sizeof(T) * count);
+    return off <= cap ? p : nullptr;
+  }
+};
+
 // Builds the binary tree by PLOC over the Morton order `order` (n >= 2).  Fills children[] / node_boxes[] (n - 1 slots, the
 // root is the last node created) and *root.  *ok = false when the pass limit is hit (the caller falls back to the radix tree).
+static size_t ploc_scratch_bytes(uint32_t n, size_t* scan_bytes_out) {
+  size_t scan_bytes = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0);
+  *scan_bytes_out = scan_bytes;
+  return 2 * (Arena::pad(sizeof(uint32_t) * (size_t)n) + Arena::pad(sizeof(Box) * (size_t)n)) + 5 * Arena::pad(sizeof(uint32_t) * (size_t)n) +
+         Arena::pad(2 * sizeof(uint32_t)) + Arena::pad(scan_bytes);
+}
 static hipError_t ploc_build(hipStream_t s, uint32_t n, const Box* leaf_boxes, const uint32_t* order, uint2* children, Box* node_boxes,
-                             uint32_t* root, bool* ok) {
+                             uint32_t* root, bool* ok, Arena& arena, size_t scan_bytes) {
   hipError_t err = hipSuccess;
   *ok = false;
   uint32_t* cl_ref[2] = {nullptr, nullptr}; Box* cl_box[2] = {nullptr, nullptr};
   uint32_t *nn = nullptr, *merge_flag = nullptr, *keep_flag = nullptr, *node_off = nullptr, *pos = nullptr, *counts = nullptr;
-  void* scan_tmp = nullptr; size_t scan_bytes = 0;
+  void* scan_tmp = nullptr;
   uint32_t cur = n, base = 0, passes = 0;
   int a = 0;
-  for (int k = 0; k < 2; k++) { LB_CHECK(hipMalloc(&cl_ref[k], sizeof(uint32_t) * (size_t)n)); LB_CHECK(hipMalloc(&cl_box[k], sizeof(Box) * (size_t)n)); }
-  LB_CHECK(hipMalloc(&nn, sizeof(uint32_t) * (size_t)n)); LB_CHECK(hipMalloc(&merge_flag, sizeof(uint32_t) * (size_t)n));
-  LB_CHECK(hipMalloc(&keep_flag, sizeof(uint32_t) * (size_t)n)); LB_CHECK(hipMalloc(&node_off, sizeof(uint32_t) * (size_t)n));
-  LB_CHECK(hipMalloc(&pos, sizeof(uint32_t) * (size_t)n)); LB_CHECK(hipMalloc(&counts, 2 * sizeof(uint32_t)));
-  LB_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, merge_flag, node_off, (int)n, s));
-  LB_CHECK(hipMalloc(&scan_tmp, scan_bytes));
+  const size_t mark = arena.off;  // (the radix-tree fallback reuses the arena: everything taken here is handed back on return)
+  for (int k = 0; k < 2; k++) { cl_ref[k] = arena.take<uint32_t>(n); cl_box[k] = arena.take<Box>(n); }
+  nn = arena.take<uint32_t>(n); merge_flag = arena.take<uint32_t>(n); keep_flag = arena.take<uint32_t>(n); node_off = arena.take<uint32_t>(n);
+  pos = arena.take<uint32_t>(n); counts = arena.take<uint32_t>(2);
+  scan_tmp = arena.take<char>(scan_bytes);
+  if (!scan_tmp && scan_bytes) { arena.off = mark; return hipErrorOutOfMemory; }
   hipLaunchKernelGGL(k_ploc_init, dim3((n + 255) / 256), dim3(256), 0, s, n, leaf_boxes, order, cl_ref[0], cl_box[0]);
   while (cur > 1) {
     if (++passes > 256) goto done;  // >= 1 merge per pass is guaranteed, ~30 % per pass is typical: this is a degenerate input
@@ -423,9 +443,7 @@ static hipError_t ploc_build(hipStream_t s, uint32_t n, const Box* leaf_boxes, c
     *ok = true;
   }
 done:
-  for (int k = 0; k < 2; k++) { (void)hipFree(cl_ref[k]); (void)hipFree(cl_box[k]); }
-  (void)hipFree(nn); (void)hipFree(merge_flag); (void)hipFree(keep_flag); (void)hipFree(node_off); (void)hipFree(pos); (void)hipFree(counts);
-  (void)hipFree(scan_tmp);
+  arena.off = mark;
   return err;
 }
 
@@ -446,9 +464,10 @@ static hipError_t build_tree(hipStream_t s, uint32_t n, const Box* leaf_boxes, u
   Box* node_boxes = nullptr;
   uint64_t *keys_a = nullptr, *keys_b = nullptr; uint32_t *vals_a = nullptr, *vals_b = nullptr;
   uint2 *children = nullptr, *queue[2] = {nullptr, nullptr}; uint32_t *parent_int = nullptr, *parent_leaf = nullptr, *flags = nullptr;
-  int* bounds = nullptr; uint32_t* counters = nullptr; void* sort_tmp = nullptr; size_t sort_bytes = 0;
+  int* bounds = nullptr; uint32_t* counters = nullptr; void* sort_tmp = nullptr; size_t sort_bytes = 0, scan_bytes = 0;
   uint32_t depth_h[2] = {0, 0};
   uint32_t root = 0, binary_depth = 0;
+  Arena arena;
 
   if (n == 1) {
     const uint32_t zero = 0;
@@ -457,31 +476,36 @@ static hipError_t build_tree(hipStream_t s, uint32_t n, const Box* leaf_boxes, u
     info->root_ref = leaf_tag | 0u;
     return hipSuccess;
   }
-  LB_CHECK(hipMalloc(&bounds, sizeof(int) * 8));
-  LB_CHECK(hipMalloc(&counters, 4 * sizeof(uint32_t)));  // [0] max binary depth, [1] emitted (fallback), [2] next level size, [3] unused
+  LB_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 63, s));
+  {
+    const size_t N = n;
+    arena.cap = Arena::pad(sizeof(int) * 8) + Arena::pad(4 * sizeof(uint32_t)) + 2 * Arena::pad(sizeof(uint64_t) * N) + 2 * Arena::pad(sizeof(uint32_t) * N) +
+                Arena::pad(sizeof(uint2) * (N - 1)) + Arena::pad(sizeof(uint32_t) * (N - 1)) + Arena::pad(sizeof(uint32_t) * N) + Arena::pad(sizeof(uint32_t) * (N - 1)) +
+                Arena::pad(sizeof(Box) * (N - 1)) + 2 * Arena::pad(sizeof(uint2) * N) + Arena::pad(sort_bytes) + ploc_scratch_bytes(n, &scan_bytes);
+    LB_CHECK(hipMalloc((void**)&arena.base, arena.cap));
+  }
+  bounds = arena.take<int>(8);
+  counters = arena.take<uint32_t>(4);  // [0] max binary depth, [1] emitted (fallback), [2] next level size, [3] unused
   LB_CHECK(hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), s));
-  LB_CHECK(hipMalloc(&keys_a, sizeof(uint64_t) * (size_t)n));
-  LB_CHECK(hipMalloc(&keys_b, sizeof(uint64_t) * (size_t)n));
-  LB_CHECK(hipMalloc(&vals_a, sizeof(uint32_t) * (size_t)n));
-  LB_CHECK(hipMalloc(&vals_b, sizeof(uint32_t) * (size_t)n));
-  LB_CHECK(hipMalloc(&children, sizeof(uint2) * (size_t)(n - 1)));
-  LB_CHECK(hipMalloc(&parent_int, sizeof(uint32_t) * (size_t)(n - 1)));
-  LB_CHECK(hipMalloc(&parent_leaf, sizeof(uint32_t) * (size_t)n));
-  LB_CHECK(hipMalloc(&flags, sizeof(uint32_t) * (size_t)(n - 1)));
-  LB_CHECK(hipMalloc(&node_boxes, sizeof(Box) * (size_t)(n - 1)));
-  for (int k = 0; k < 2; k++) LB_CHECK(hipMalloc(&queue[k], sizeof(uint2) * (size_t)n));
+  keys_a = arena.take<uint64_t>(n); keys_b = arena.take<uint64_t>(n);
+  vals_a = arena.take<uint32_t>(n); vals_b = arena.take<uint32_t>(n);
+  children = arena.take<uint2>(n - 1);
+  parent_int = arena.take<uint32_t>(n - 1);
+  parent_leaf = arena.take<uint32_t>(n);
+  flags = arena.take<uint32_t>(n - 1);
+  node_boxes = arena.take<Box>(n - 1);
+  for (int k = 0; k < 2; k++) queue[k] = arena.take<uint2>(n);
+  sort_tmp = arena.take<char>(sort_bytes);
 
   hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, s, bounds);
   hipLaunchKernelGGL(k_bounds, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, s, leaf_boxes, n, bounds);
   hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, s, leaf_boxes, n, bounds, keys_a, vals_a);
-  LB_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 63, s));
-  LB_CHECK(hipMalloc(&sort_tmp, sort_bytes));
   LB_CHECK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 63, s));
 
   for (;;) {
     if (use_ploc) {
       bool ok = false;
-      LB_CHECK(ploc_build(s, n, leaf_boxes, vals_b, children, node_boxes, &root, &ok));
+      LB_CHECK(ploc_build(s, n, leaf_boxes, vals_b, children, node_boxes, &root, &ok, arena, scan_bytes));
       if (!ok) { use_ploc = false; continue; }
     } else {
       LB_CHECK(hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)(n - 1), s));
@@ -534,9 +558,7 @@ static hipError_t build_tree(hipStream_t s, uint32_t n, const Box* leaf_boxes, u
   }
 
 done:
-  (void)hipFree(node_boxes); (void)hipFree(keys_a); (void)hipFree(keys_b); (void)hipFree(vals_a); (void)hipFree(vals_b); (void)hipFree(children);
-  (void)hipFree(parent_int); (void)hipFree(parent_leaf); (void)hipFree(flags); (void)hipFree(bounds); (void)hipFree(counters); (void)hipFree(sort_tmp);
-  (void)hipFree(queue[0]); (void)hipFree(queue[1]);
+  if (arena.base) (void)hipFree(arena.base);
   return err;
 }
 
@@ -554,11 +576,15 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
   TreeInfo info;
   const bool use_ploc = getenv("PTAMD_RADIX_TREE") == nullptr;  // PLOC by default; the Karras radix tree is the fallback
 
-  LB_CHECK(hipMalloc(&tris_tmp, sizeof(TriRec) * (size_t)n));
+  Arena tmp;  // the flattening's temporaries in one allocation
+  tmp.cap = Arena::pad(sizeof(TriRec) * (size_t)n) + Arena::pad(sizeof(Box) * (size_t)n) + Arena::pad(sizeof(uint32_t) * (size_t)n) +
+            Arena::pad(sizeof(BvhNode) * (size_t)(n > 1 ? n - 1 : 1));
+  LB_CHECK(hipMalloc((void**)&tmp.base, tmp.cap));
+  tris_tmp = tmp.take<TriRec>(n);
+  leaf_boxes = tmp.take<Box>(n);
+  order = tmp.take<uint32_t>(n);
+  nodes_tmp = tmp.take<BvhNode>(n > 1 ? n - 1 : 1);
   LB_CHECK(hipMalloc(&out->tris, sizeof(TriRec) * (size_t)n));
-  LB_CHECK(hipMalloc(&leaf_boxes, sizeof(Box) * (size_t)n));
-  LB_CHECK(hipMalloc(&order, sizeof(uint32_t) * (size_t)n));
-  if (n > 1) LB_CHECK(hipMalloc(&nodes_tmp, sizeof(BvhNode) * (size_t)(n - 1)));
   hipLaunchKernelGGL(k_flatten, dim3(blocks), dim3(256), 0, s, S, instance_count, n, tris_tmp, leaf_boxes);
   LB_CHECK(build_tree(s, n, leaf_boxes, stack_capacity, use_ploc, nodes_tmp, 0u, kLeafBit, false, order, &info));
   hipLaunchKernelGGL(k_reorder_tris, dim3(blocks), dim3(256), 0, s, (int)n, order, tris_tmp, out->tris);  // triangles in leaf (Morton) order
@@ -573,7 +599,7 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
   out->depth4 = info.depth4;
 
 done:
-  (void)hipFree(tris_tmp); (void)hipFree(leaf_boxes); (void)hipFree(nodes_tmp); (void)hipFree(order);
+  if (tmp.base) (void)hipFree(tmp.base);
   if (err != hipSuccess) {
     (void)hipFree(out->nodes); (void)hipFree(out->tris);
     *out = LbvhResult{};

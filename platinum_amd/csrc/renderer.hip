@@ -400,6 +400,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    else free_b += r->queue_bytes_held();  // what the previous render's queues occupy is reused, i.e. available
     pt_queue_plan plan{};
     const char* why = "";
     const int rc = plan_queues(p->width, p->height, p->spp, p->samples_in_flight, free_b, r->tiles_per_seg_override, r->seg_bands, &plan, &why);

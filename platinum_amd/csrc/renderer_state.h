@@ -30,16 +30,24 @@ namespace {
     }                                                                                                      \
   } while (0)
 
+// A device array that KEEPS its allocation across pt_start_render calls: the frontend restarts the render on every camera or scene
+// edit (renderer_pt.cpp:199-217 makes startRender cheap), and releasing + re-allocating the ~53 GB of path queues took 1.3-1.5 s per
+// restart on MI355X (hipFree of multi-GB buffers unmaps them; measured r03) against 12 ms for everything else.  alloc() only goes back
+// to the driver when the array has to GROW; the memory is returned in pt_destroy.
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
-  size_t n = 0;
+  size_t n = 0;    // elements in use
+  size_t cap = 0;  // elements allocated
   hipError_t alloc(size_t count) {
+    if (count <= cap) { n = count; return hipSuccess; }
     release();
-    n = count;
-    if (count == 0) return hipSuccess;
-    return hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * count);
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * count);
+    if (e != hipSuccess) { p = nullptr; return e; }
+    n = cap = count;
+    return hipSuccess;
   }
+  size_t bytes_held() const { return cap * sizeof(T); }
   hipError_t upload(const std::vector<T>& v) {
     hipError_t e = alloc(v.size());
     if (e != hipSuccess || v.empty()) return e;
@@ -48,7 +56,7 @@ struct DevBuf {
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
-    n = 0;
+    n = cap = 0;
   }
   ~DevBuf() { release(); }
 };
@@ -145,19 +153,30 @@ struct pt_renderer {
   ShadowQueue shadow_queue() { return ShadowQueue{sq_o.p, sq_d.p, sq_c.p}; }
   Segments segments() { return Segments{{seg_active[0].p, seg_active[1].p}, seg_shadow.p, wave_stats.p, chunk_table[0].p, chunk_table[1].p, seg_cap, nseg, tiles_per_seg, /*nsamples: set per batch*/ 0u, seg_bands, nstats, refill_threshold}; }
 
+  // A restart keeps every device array (they are re-filled, and only re-allocated when they must grow); what it drops is the
+  // acceleration structure of the previous scene and the "started" state.  release_all() returns the memory (pt_destroy).
   void free_scene() {
-    positions.release(); vdata.release(); indices.release(); slots.release(); meshes.release(); instances.release();
-    materials.release(); lights_d.release(); tex_pixels.release(); textures.release(); env_alias_d.release(); scene_d.release(); shade_recs.release(); light_recs.release(); light_cdf.release();
     if (bvh.nodes) (void)hipFree(bvh.nodes);
     if (bvh.tris) (void)hipFree(bvh.tris);
     if (bvh.mesh_trav) (void)hipFree(bvh.mesh_trav);
-    inst_trav.release();
     bvh = LbvhResult{};
+    acc = nullptr;
+    started = false;
+  }
+  // bytes of path-queue memory this renderer already holds (reused by the next render: they count as free when the batch is sized)
+  size_t queue_bytes_held() const {
+    size_t b = hit.bytes_held() + sq_o.bytes_held() + sq_d.bytes_held() + sq_c.bytes_held() + Lbuf.bytes_held() + chunk_table[0].bytes_held() + chunk_table[1].bytes_held();
+    for (int k = 0; k < 2; k++) b += st_rayO[k].bytes_held() + st_rayD[k].bytes_held() + st_att[k].bytes_held();
+    return b;
+  }
+  void release_all() {
+    free_scene();
+    positions.release(); vdata.release(); indices.release(); slots.release(); meshes.release(); instances.release();
+    materials.release(); lights_d.release(); tex_pixels.release(); textures.release(); env_alias_d.release(); scene_d.release(); shade_recs.release(); light_recs.release(); light_cdf.release();
+    inst_trav.release();
     for (int k = 0; k < 2; k++) { st_rayO[k].release(); st_rayD[k].release(); st_att[k].release(); }
     seg_active[0].release(); seg_active[1].release(); seg_shadow.release(); wave_stats.release(); chunk_table[0].release(); chunk_table[1].release(); gmon_buckets_d.release(); render_target.release();
     hit.release(); sq_o.release(); sq_d.release(); sq_c.release(); Lbuf.release(); acc_own.release(); spill.release();
-    acc = nullptr;
-    started = false;
   }
   void drop_timed() {
     for (auto& t : timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
