@@ -7,7 +7,8 @@
  *   reference member (renderer_pt.hpp)                          here
  *   Renderer(MTL::Device*, MTL::CommandQueue*, Store&) noexcept  Renderer(int device) / Renderer(std::vector<int> devices) noexcept
  *   ~Renderer()                                            :34   ~Renderer()
- *   void render()                                          :36   void render()                 one sample per call, returns at once
+ *   void render()                                          :36   void render()                 one sample per call (merged into batches by the
+ *                                                                                               library while the GPU is busy), returns at once
  *   void startRender(cameraNodeId, viewportSize, sampleCount,
  *                    gmonBuckets, workingSpace, flags = 0) :38   void startRender(scene, viewportSize, sampleCount, gmonBuckets,
  *                                                                                 workingSpace, flags = 0)
@@ -63,11 +64,14 @@ public:
   Renderer& operator=(const Renderer&) = delete;
   ~Renderer() { if (m_pt) pt_destroy(m_pt); }
 
-  // renderer_pt.cpp:113-197 steady state: one more sample of every pixel is enqueued (on EVERY device of a group: N samples);
-  // does not wait.
+  // renderer_pt.cpp:113-197 steady state: one more sample of every pixel is accepted (on EVERY device of a group: N samples);
+  // does not wait.  Calls that arrive while the GPU is busy are merged into batches by the library (ptamd.h pt_render_step), so
+  // a tight `while (status() & Status_Busy) render();` loop runs at the full batch rate.  A frontend that calls render() once per
+  // vsync is limited to refresh-rate samples per second by that loop itself (the reference's structural ceiling, BASELINE.md §1:
+  // 60 spp/s where an MI355X traces ~950 on C3); setSamplesPerRender(n) lets such a loop accept n samples per call.
   void render() {
     if (!m_pt || !m_started) return;
-    check(pt_render_step(m_pt, 1));
+    check(pt_render_step(m_pt, m_samplesPerRender));
   }
 
   // renderer_pt.cpp:199-217 + the rebuild half of the first render() (:72-111): the scene is copied to the device, light table,
@@ -135,6 +139,7 @@ public:
   void setMaxBounces(uint32_t b) { m_maxBounces = b; }              // kernel.metal:5 MAX_BOUNCES = 50 (the default here too)
   void setFirstSample(uint32_t s) { m_firstSample = s; }            // frameIdx of the first sample: sample-range shards
   void setSamplesInFlight(uint32_t s) { m_samplesInFlight = s; }    // 0 = automatic
+  void setSamplesPerRender(uint32_t n) { m_samplesPerRender = n ? n : 1; }  // samples one render() call accepts; 1 = the reference
   void setNonfinitePolicy(uint32_t p) { m_nonfinitePolicy = p; }    // PT_NONFINITE_*
   void setAccelStructure(uint32_t a) { m_accelStructure = a; }      // PT_ACCEL_*
   // The float accumulator (renderer_pt.cpp:812-821): W*H RGBA32F running mean, alpha 1 — the parity surface.  Blocks.
@@ -180,6 +185,7 @@ private:
   uint2 m_size{1, 1};
   uint32_t m_selectedPipeline = uint32_t(Integrators::MIS);  // renderer_pt.hpp:98
   uint32_t m_maxBounces = 50, m_firstSample = 0, m_samplesInFlight = 0, m_nonfinitePolicy = 0, m_accelStructure = PT_ACCEL_AUTO;
+  uint32_t m_samplesPerRender = 1;
   pt_post_options m_postOptions{};
   pt_tonemap_options m_tonemapOptions{};
   pt_gmon_options m_gmonOptions{1.0f};
