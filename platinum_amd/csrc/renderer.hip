@@ -466,7 +466,11 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
 int flush_pending(pt_renderer* r, bool all) {
   while (r->launched < r->accumulated) {
     const uint64_t pending = r->accumulated - r->launched;
-    const bool idle = !r->batch_done_valid || hipEventQuery(r->batch_done) == hipSuccess;
+    bool idle = true;
+    if (r->batch_done_valid && hipEventQuery(r->batch_done) != hipSuccess) {
+      idle = false;
+      (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure: do not leave it for the next hipGetLastError() check
+    }
     if (!all && !idle && pending < r->samples_in_flight) break;
     const uint32_t ns = (uint32_t)std::min<uint64_t>(pending, r->samples_in_flight);
     const int rc = enqueue_batch(r, r->params.first_sample + (uint32_t)r->launched, ns, (uint32_t)r->launched, BATCH_RENDER, nullptr);
