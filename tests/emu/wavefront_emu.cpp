@@ -468,6 +468,7 @@ uint32_t emu_get_lights(void* h, pt_area_light* out, uint32_t cap) {
 // with and without that test, and counts node fetches.  Harness-only; nothing here is compiled into libptamd.so.
 struct ProbeCounts { unsigned long long nodes = 0, nodes_cull = 0, tris = 0, tris_cull = 0, rays = 0, mismatch = 0; };
 static ProbeCounts g_probe;
+static unsigned long long g_stack_hist[64] = {0};  // pushes by the stack depth they write to (non-culling probe)
 static RayHit probe_closest(const DeviceScene& S, vec3 o, vec3 d, float tmin, float tmax, bool cull, unsigned long long* nodes, unsigned long long* tris) {
   RayHit best; best.t = tmax; best.u = best.v = 0; best.tri = kInvalidRef; best.gid = kInvalidRef;
   if (S.root_ref == kInvalidRef) return best;
@@ -509,7 +510,7 @@ static RayHit probe_closest(const DeviceScene& S, vec3 o, vec3 d, float tmin, fl
     }
     for (int k = 0; k < nl; k++) test_tri(leaves[k]);
     std::stable_sort(inner, inner + ni, [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first < b.first; });
-    for (int k = ni - 1; k >= 1; k--) stack.push_back({inner[k].second, inner[k].first});
+    for (int k = ni - 1; k >= 1; k--) { if (!cull) g_stack_hist[stack.size() < 63 ? stack.size() : 63]++; stack.push_back({inner[k].second, inner[k].first}); }
     if (ni > 0) { cur = inner[0].second; continue; }
     bool got = false;
     while (!stack.empty()) {
@@ -687,6 +688,7 @@ void emu_get_wide(double out[26]) {
   out[24] = (double)g_wide.rays; out[25] = (double)g_wide.mismatch;
   g_wide = WideCounts{};
 }
+void emu_get_stack_hist(unsigned long long out[64]) { for (int i = 0; i < 64; i++) { out[i] = g_stack_hist[i]; g_stack_hist[i] = 0; } }
 void emu_get_probe(unsigned long long out[6]) {
   out[0] = g_probe.nodes; out[1] = g_probe.nodes_cull; out[2] = g_probe.tris; out[3] = g_probe.tris_cull; out[4] = g_probe.rays; out[5] = g_probe.mismatch;
   g_probe = ProbeCounts{};
