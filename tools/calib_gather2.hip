@@ -11,6 +11,8 @@
 //           back with 4 x ds_read_b128 (what a traversal kernel would do to hand every lane a whole node)
 //   mode 6  lane-private 4 B:          one dword per lane
 //   mode 7  pair-cooperative 32-B:     lanes 2q, 2q+1 read the halves of one 32-B record
+//   mode 8  column-cooperative 64-B:   lanes l, l+16, l+32, l+48 (one lane per 16-lane row) read the four parts of ONE record in one
+//                                       instruction: would the L1 merge them too?  (a transposition across ROWS is 4x cheaper: v_permlane*_swap)
 // `inflight` independent records (modes 0,3,4,6: per lane; modes 1,2,5,7: instructions) are issued before any result is used.
 //   ./calib_gather2 <mode> <table_MiB> <records_per_lane_or_instr_groups> <inflight 1|2|4|8|16>
 // prints one JSON line: records/s, bytes/s, "lane-addresses"/s (active lanes x load instructions).
@@ -36,6 +38,7 @@ __global__ void __launch_bounds__(256) k_gather(const uint4* __restrict__ table,
   u64 xq = (u64)(wave * 64u + (lane >> 2)) * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;          // per-quad stream
   u64 xo = (u64)(wave * 64u + (lane >> 3)) * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull;          // per-oct stream
   u64 xp = (u64)(wave * 64u + (lane >> 1)) * 0x9E3779B97F4A7C15ull + 0x14057B7EF767814Full;          // per-pair stream
+  u64 xc = (u64)(wave * 64u + (lane & 15u)) * 0x9E3779B97F4A7C15ull + 0x3C6EF372FE94F82Bull;         // per-column stream
   uint4 acc = {0, 0, 0, 0};
   constexpr int G = INFL > 2 ? 2 : INFL;                     // mode 5: groups of 64 records in flight per wave
   __shared__ uint4 stage[MODE == 5 ? 4 * 256 * G : 1];        //         4 waves x G x 4 KiB
@@ -71,6 +74,10 @@ __global__ void __launch_bounds__(256) k_gather(const uint4* __restrict__ table,
     } else if (MODE == 7) {
       uint4 v[INFL];
       for (int k = 0; k < INFL; k++) v[k] = table[(size_t)pick(xp, nrec) * 2 + (lane & 1u)];
+      for (int k = 0; k < INFL; k++) { acc.x ^= v[k].x ^ v[k].w; acc.y += v[k].y + v[k].z; }
+    } else if (MODE == 8) {
+      uint4 v[INFL];
+      for (int k = 0; k < INFL; k++) v[k] = table[(size_t)pick(xc, nrec) * 4 + (lane >> 4)];
       for (int k = 0; k < INFL; k++) { acc.x ^= v[k].x ^ v[k].w; acc.y += v[k].y + v[k].z; }
     } else if (MODE == 5) {
       // INFL groups of 4 LDS-DMA instructions: group g brings 64 records (one per lane of the wave) into 4 KiB of LDS
@@ -135,7 +142,8 @@ int main(int argc, char** argv) {
       case 4: launch<4>(infl, blocks, table, nrec, it, sink); break;
       case 5: launch<5>(infl, blocks, table, nrec, it, sink); break;
       case 6: launch<6>(infl, blocks, table, nrec, it, sink); break;
-      default: launch<7>(infl, blocks, table, nrec, it, sink); break;
+      case 7: launch<7>(infl, blocks, table, nrec, it, sink); break;
+      default: launch<8>(infl, blocks, table, nrec, it, sink); break;
     }
   };
   go(1);  // warm-up (also brings a small table into the L2s)
@@ -154,7 +162,7 @@ int main(int argc, char** argv) {
   const double n_it = (double)iters * infl;
   switch (mode) {
     case 0: recs = lanes * n_it; lane_addr = recs * 4; break;
-    case 1: recs = waves * 16 * n_it; lane_addr = waves * 64 * n_it; break;
+    case 1: case 8: recs = waves * 16 * n_it; lane_addr = waves * 64 * n_it; break;
     case 2: recs = waves * 8 * n_it; lane_addr = waves * 64 * n_it; break;
     case 3: recs = lanes * n_it; lane_addr = recs * 8; break;
     case 4: recs = lanes * n_it; lane_addr = recs; break;
