@@ -190,6 +190,39 @@ def test_merged_render_calls_with_gmon_resolve_like_one_step(gpu_renderer):
     assert np.array_equal(r.readbackAccumulator().view(np.uint32), mid.view(np.uint32))
 
 
+def test_restarts_reuse_device_arrays_across_sizes_scenes_and_modes():
+    """r03: device arrays are kept across pt_start_render (a restart took 1.3-1.5 s when they were released and re-allocated) and
+    only re-allocated to grow.  A renderer that has been through bigger / smaller images, other scenes, GMoN and the two-level
+    structure must give the same bits as a fresh one — nothing stale may leak from a longer array into a shorter use."""
+    from platinum_amd import Renderer
+    seq = [
+        ("cornell", 64, 64, 3, 4, {}),
+        ("field8", 256, 128, 4, 6, {"samples_in_flight": 4}),
+        ("cornell_sphere", 96, 54, 5, 8, {"gmonBuckets": 5, "flags": abi.FLAG_MULTISCATTER_GGX | abi.FLAG_GMON}),
+        ("cornell", 64, 64, 3, 4, {}),
+        ("field8", 40, 24, 2, 5, {"accel_structure": abi.ACCEL_TWO_LEVEL}),
+        ("field8", 256, 128, 4, 6, {"samples_in_flight": 2}),
+    ]
+    def render(r, name, w, h, spp, B, kw):
+        r.startRender(_scene(name), (w, h), spp, max_bounces=B, **kw)
+        r.render(0)
+        return r.readbackAccumulator().copy(), r.readbackRenderTarget().copy()
+    veteran = Renderer(device=0)
+    try:
+        got = [render(veteran, *c) for c in seq]
+    finally:
+        veteran.close()
+    for c, (acc, img) in zip(seq, got):
+        fresh = Renderer(device=0)
+        try:
+            ref_acc, ref_img = render(fresh, *c)
+        finally:
+            fresh.close()
+        assert np.array_equal(acc.view(np.uint32), ref_acc.view(np.uint32)), c[:5]
+        assert np.array_equal(img, ref_img), c[:5]
+    assert np.array_equal(got[0][0].view(np.uint32), got[3][0].view(np.uint32))   # the same render before and after the others
+
+
 def test_sample_sharding_is_the_same_sample_set(gpu_renderer):
     """§8e: renderers with disjoint first_sample ranges together trace exactly the samples of one big render."""
     sc = _scene("cornell_sphere")
