@@ -132,7 +132,7 @@ def test_one_sample_render_calls_are_merged_into_batches_and_give_the_same_image
     Calls that arrive while the GPU is busy are merged into batches (renderer.hip flush_pending); the accumulator is
     bit-identical to one big step, progress counts accepted samples, and nothing stays pending once the render is Done."""
     sc = _scene("cornell_sphere")
-    w, h, spp, B = 320, 180, 48, 6
+    w, h, spp, B = 1280, 720, 48, 6   # (a one-sample batch of this size keeps the GPU busy for milliseconds: many host calls long)
     r = gpu_renderer
     _start(r, sc, w, h, spp, B, samples_in_flight=16)
     r.render(0)
