@@ -259,6 +259,14 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   r->params = *p;
   r->stream = p->stream ? (hipStream_t)p->stream : r->own_stream;
   const auto t_up0 = std::chrono::steady_clock::now();
+  const bool phase_log = getenv("PTAMD_START_PHASES") != nullptr;   // analysis aid: where a (re)start spends its wall time
+  auto phase = [&, t_last = std::chrono::steady_clock::now()](const char* what) mutable {
+    if (!phase_log) return;
+    (void)hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "ptamd start: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
 
   // ---- flatten the snapshot, derive constants and the light table (host_scene.h) ----
   HostScene hs;
@@ -268,6 +276,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
     if (rc != PT_OK) return fail(rc, err);
   }
   if (hs.tri_count >= (1u << 28)) return fail(PT_ERR_UNSUPPORTED, "more than 2^28 flattened triangles (the hit record keeps 28 bits for the triangle)");
+  phase("host flatten + light table");
   r->instance_count = (uint32_t)hs.instances.size();
   r->tri_count = hs.tri_count;
   r->constants = hs.constants;
@@ -309,6 +318,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   S.max_bounces = p->max_bounces;
   S.tri_count = r->tri_count;
   S.root_ref = kInvalidRef;
+  phase("upload");
   PT_HIP(hipDeviceSynchronize());
   r->upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count();
 
@@ -381,6 +391,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
     S.inst_trav = r->inst_trav.p;
     S.mesh_trav = r->bvh.mesh_trav;
   }
+  phase("acceleration structure");
   PT_HIP(r->shade_recs.alloc(r->tri_count));
   S.shade_recs = r->shade_recs.p;
   launch_shade_records(r->stream, S, r->shade_recs.p);
@@ -392,6 +403,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   PT_HIP(r->scene_d.upload(std::vector<DeviceScene>(1, S)));  // k_shade reads the table from memory (scalar loads)
 
   // ---- wavefront buffers ----
+  phase("shade / light records");
   const uint64_t npix = (uint64_t)p->width * p->height;
   // Queue segments (kernels.hip): one per 8x8 tile (a few tiles each once the image has more than 32640 of them), each with
   // room for its tiles under all samples in flight; queue_plan.h holds the sizing and every index-width limit.  The producers
@@ -444,6 +456,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   PT_HIP(hipMemsetAsync(r->totals.p, 0, sizeof(Totals), r->stream));
   PT_HIP(hipStreamSynchronize(r->stream));
 
+  phase("queues + accumulator");
   for (int k = 0; k < K_CLASSES; k++) { r->ms_class[k] = 0; r->launches[k] = 0; }
   r->accumulated = 0;
   r->launched = 0;
