@@ -480,7 +480,12 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
         if (k < n) {
           w = f2u(hit[seg_slot(seg.nseg, sg, k)].w);
           cls = w == kInvalidRef ? 4u : (w >> 28) & 3u;
-          if (cls == 4u && S.env_texture < 0) cls = 5u;  // a miss without an environment adds nothing (defs.metal:21)
+          // a miss without an environment adds attenuation * backgroundColor = attenuation * 0 (kernel.metal:311 / :541, defs.metal:21):
+          // nothing — unless the BSDF has driven the throughput to an infinity or a NaN (a zero pdf), when the reference's sum turns NaN
+          if (w == kInvalidRef && S.env_texture < 0) {
+            const vec4 a4 = sin.att[seg_slot(seg.nseg, sg, k)];
+            if (!att_poisoned(v3(a4.x, a4.y, a4.z))) cls = 5u;
+          }
         }
         const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3),
                                  m4 = __ballot(cls == 4);
@@ -527,10 +532,15 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
         const vec4 o4 = sin.rayO[i];
         const vec4 d4 = sin.rayD[i];
         const vec4 a4 = sin.att[i];
-        const vec3 Le = stage_miss(S, v3(d4.x, d4.y, d4.z), v3(a4.x, a4.y, a4.z), bounce, o4.w, (f2u(d4.w) & kMetaSpecular) != 0);
+        const vec3 att = v3(a4.x, a4.y, a4.z);
         const uint32_t mpid = lbuf_base + (f2u(d4.w) >> kMetaPidShift);
         vec4 L = Lbuf[mpid];
-        L.x += Le.x; L.y += Le.y; L.z += Le.z;
+        if (S.env_texture >= 0) {
+          const vec3 Le = stage_miss(S, v3(d4.x, d4.y, d4.z), att, bounce, o4.w, (f2u(d4.w) & kMetaSpecular) != 0);
+          L.x += Le.x; L.y += Le.y; L.z += Le.z;
+        }
+        // L += attenuation * backgroundColor (kernel.metal:311 / :541; backgroundColor = 0): + 0 for a finite throughput, NaN otherwise
+        L.x += att.x * 0.0f; L.y += att.y * 0.0f; L.z += att.z * 0.0f;
         Lbuf[mpid] = L;
       }
       uint32_t c_shadow = 0, c_alive = 0;  // written by the lanes inside the divergent region, made wave-uniform after it

@@ -341,6 +341,8 @@ struct BounceOut {
   bool next_specular;
   uint32_t dim;
 };
+// a throughput with a NaN or an infinity in it (conservative: also the last finite binade) — see k_shade's scan of the misses
+PT_HD bool att_poisoned(vec3 a) { return !(fabsf(a.x) <= 3.0e38f && fabsf(a.y) <= 3.0e38f && fabsf(a.z) <= 3.0e38f); }
 PT_HD BounceOut shade_bounce(const DeviceScene& S, const ShadeTables& T, const ShadeIn& in, const ShadeGeom& g, const ShadingContext& ctx,
                              const BSDF& bsdf, uint32_t dim_rr) {
   BounceOut out;

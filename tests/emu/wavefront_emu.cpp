@@ -564,6 +564,7 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
         if (hits && hit.tri != kInvalidRef) { hits[((size_t)b * NP + pid) * 2] = S.tris[hit.tri].inst; hits[((size_t)b * NP + pid) * 2 + 1] = S.tris[hit.tri].prim; }
         if (hit.tri == kInvalidRef) {
           if (S.env_texture >= 0) L = L + stage_miss(S, d, att, b, lastPdf, lastSpec);
+          L = L + att * 0.0f;  // attenuation * backgroundColor (kernel.metal:311 / :541): NaN for a throughput that is not finite
           break;
         }
         const vec4 qO{o.x, o.y, o.z, lastPdf}, qD{d.x, d.y, d.z, 0.0f};  // the queue entry the stage may re-read

@@ -223,6 +223,28 @@ def test_restarts_reuse_device_arrays_across_sizes_scenes_and_modes():
     assert np.array_equal(got[0][0].view(np.uint32), got[3][0].view(np.uint32))   # the same render before and after the others
 
 
+@pytest.mark.parametrize("seed", [24, 648, 996])
+def test_escaping_path_with_a_non_finite_throughput_gets_the_references_nan(gpu_renderer, seed):
+    """Found by the r03 fuzz sweep (tests/fuzz_parity_sweep.py: 3 pixels in 1 000 random scenes, then 0 in 2 000 after the fix).  The
+    reference adds `attenuation * backgroundColor` (= attenuation * 0, kernel.metal:311 / :541, defs.metal:21) to every path that
+    escapes.  When the BSDF has driven the throughput to inf or NaN (a zero pdf) that term is NaN; the wavefront used to skip the
+    misses of scenes without an environment (radiance 0 instead of NaN) and to leave out the term after the environment's radiance
+    (inf instead of NaN).  Now a path whose throughput is not finite carries its miss processed by k_shade (whose scan of a scene without an environment reads the throughput of the escaping paths)."""
+    sc = scenes.random_scene(seed)
+    w, h, B, spp = 71, 45, 3 + seed % 7, 2 + seed % 2
+    p = _start(gpu_renderer, sc, w, h, spp, B, integrator=abi.INTEGRATOR_SIMPLE, samples_in_flight=1 + seed % 3)
+    o = oracle_lib.OracleScene(sc, p)
+    saw_nan = False
+    for s in range(spp):
+        rg, hg = gpu_renderer.debugSample(s)
+        rc, hc = o.debug_sample(s)
+        assert np.array_equal(hg, hc) and _same_bits_or_both_nan(rg, rc), s
+        saw_nan = saw_nan or bool(np.isnan(rc).any())
+    assert saw_nan   # (the scene still produces the case)
+    gpu_renderer.render(0)
+    assert _same_bits_or_both_nan(gpu_renderer.readbackAccumulator(), o.render(0, spp))
+
+
 def test_sample_sharding_is_the_same_sample_set(gpu_renderer):
     """§8e: renderers with disjoint first_sample ranges together trace exactly the samples of one big render."""
     sc = _scene("cornell_sphere")
