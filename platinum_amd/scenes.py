@@ -561,11 +561,14 @@ def textured_scene(env=True, area_light=True, alpha=True):
     return sc
 
 
-def random_scene(seed, textures=True):
+def random_scene(seed, textures=True, extras=False):
     """A seeded random scene for parity fuzzing: 2-10 instances of the reference primitives under arbitrary TRS (non-uniform and
     mirrored scales included), materials drawn over the whole parameter space of core/material.hpp (exact 0 / 1 corner values
-    over-represented: smooth surfaces, pure metal, pure glass), random light panels, optional textures and environment."""
+    over-represented: smooth surfaces, pure metal, pure glass), random light panels, optional textures and environment.
+    `extras` adds, from a second generator (the base scene of a seed stays what it was): the transmission / clearcoat / emission
+    texture slots, anisotropy rotation, emission-textured lights, degenerate material corners (ior 1, black base colour)."""
     rng = np.random.default_rng(seed)
+    rx = np.random.default_rng(seed + 1000003) if extras else None
     sc = Scene(name=f"random{seed}")
     meshes = [sc.add_mesh(plane(2.0)), sc.add_mesh(cube(1.0)), sc.add_mesh(sphere(0.6, 8, 12))]
     tex = []
@@ -574,6 +577,12 @@ def random_scene(seed, textures=True):
         tex.append(sc.add_texture(rng.integers(8, 256, (4, 8, 2), dtype=np.uint8), abi.TEX_RG8))
         nm = rng.integers(96, 160, (8, 8, 4), dtype=np.uint8); nm[..., 2] = 230
         tex.append(sc.add_texture(nm, abi.TEX_RGBA8))
+    xtex = []
+    if rx is not None and rx.random() < 0.7:
+        xtex.append(sc.add_texture(rx.integers(0, 256, (8, 4), dtype=np.uint8), abi.TEX_R8))        # transmission
+        xtex.append(sc.add_texture(rx.integers(0, 256, (4, 4), dtype=np.uint8), abi.TEX_R8))        # clearcoat
+        em = rx.integers(0, 256, (4, 8, 4), dtype=np.uint8); em[..., 3] = 255
+        xtex.append(sc.add_texture(em, abi.TEX_RGBA8_SRGB))                                         # emission
 
     def corner(lo=0.0, hi=1.0):
         u = rng.random()
@@ -591,6 +600,17 @@ def random_scene(seed, textures=True):
             m.base_texture = tex[0]; m.base_texture_has_alpha = bool(rng.random() < 0.3)
             if rng.random() < 0.5: m.rm_texture = tex[1]
             if rng.random() < 0.5: m.normal_texture = tex[2]
+        if rx is not None:
+            if m.anisotropy != 0.0 and rx.random() < 0.7: m.anisotropy_rotation = float(rx.uniform(0, 1))
+            if xtex and rx.random() < 0.3: m.transmission_texture = xtex[0]
+            if xtex and rx.random() < 0.3: m.clearcoat_texture = xtex[1]; m.clearcoat = max(m.clearcoat, 0.5)
+            if xtex and rx.random() < 0.15:
+                m.emission_texture = xtex[2]
+                if m.emission_strength == 0.0: m.emission = (1.0, 1.0, 1.0); m.emission_strength = float(rx.uniform(0.5, 4))
+            u = rx.random()
+            if u < 0.05: m.ior = 1.0
+            elif u < 0.10: m.base_color = (0.0, 0.0, 0.0, m.base_color[3])
+            elif u < 0.15: m.base_color = (1.0, 1.0, 1.0, m.base_color[3])
         return m
 
     sc.add_instance(meshes[0], Transform(scale=(6, 1, 6)), [material()])   # a floor so that most paths bounce

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""One-off extended fuzz (not collected by pytest): `python tests/fuzz_parity_sweep.py FIRST COUNT` runs test_random_scene_fuzz_parity's
+"""One-off extended fuzz (not collected by pytest): `python tests/fuzz_parity_sweep.py FIRST COUNT [extras]` runs test_random_scene_fuzz_parity's
 checks — constants, primary hits, per-bounce hit ids, per-sample radiance and the accumulated image of the HIP path against the oracle,
 bit for bit — on scenes.random_scene(seed) for seed in [FIRST, FIRST + COUNT), with bounce counts and image sizes varied by seed, and
-prints one JSON line.  Test infrastructure (it uses the oracle as the checker)."""
+prints one JSON line.  With `extras`: scenes.random_scene(seed, extras=True) (every texture slot, degenerate material corners) and the
+render parameters varied too (multiscatter flag, working space, first sample, samples in flight up to 5).  Test infrastructure (it uses the oracle as the checker)."""
 import json
 import os
 import sys
@@ -22,30 +23,36 @@ def same(a, b):
 
 
 def main():
-    first, count = int(sys.argv[1]), int(sys.argv[2])
+    seed0, count = int(sys.argv[1]), int(sys.argv[2])
+    extras = len(sys.argv) > 3 and sys.argv[3] == "extras"
     r = Renderer(device=0)
     bad, t0 = [], time.time()
-    for seed in range(first, first + count):
-        sc = scenes.random_scene(seed)
+    for seed in range(seed0, seed0 + count):
+        sc = scenes.random_scene(seed, extras=extras)
         integ = abi.INTEGRATOR_MIS if seed % 4 else abi.INTEGRATOR_SIMPLE
         w, h = (96, 54) if seed % 3 else (71, 45)            # (odd sizes: partial edge tiles)
         B = 3 + seed % 7
         spp = 2 + seed % 2
         accel = abi.ACCEL_TWO_LEVEL if seed % 11 == 0 else abi.ACCEL_AUTO
+        flags, space, first, sif = abi.FLAG_MULTISCATTER_GGX, scenes.BT2020, 0, 1 + seed % 3
+        if extras:
+            flags = abi.FLAG_MULTISCATTER_GGX if seed % 5 else 0
+            space = scenes.BT2020 if seed % 7 else scenes.BT709
+            first, spp, sif = (seed % 13) * 3, 2 + seed % 4, 1 + seed % 5
         r.selectKernel(integ)
-        r.startRender(sc, (w, h), spp, max_bounces=B, accel_structure=accel, samples_in_flight=1 + seed % 3)
-        p = make_params(w, h, spp, B, integrator=integ)
+        r.startRender(sc, (w, h), spp, workingSpace=space, flags=flags, max_bounces=B, first_sample=first, accel_structure=accel, samples_in_flight=sif)
+        p = make_params(w, h, spp, B, flags=flags, integrator=integ, working_space=space, first_sample=first)
         o = oracle_lib.OracleScene(sc, p)
         checks = [bytes(r.constants()) == bytes(o.constants()), r.tracePrimary(1).tobytes() == o.trace_primary(1).tobytes()]
-        rg, hg = r.debugSample(0)
-        rc, hc = o.debug_sample(0)
+        rg, hg = r.debugSample(first)
+        rc, hc = o.debug_sample(first)
         checks += [bool(np.array_equal(hg, hc)), bool(same(rg, rc))]
         r.render(0)
-        checks.append(bool(same(r.readbackAccumulator(), o.render(0, spp))))
+        checks.append(bool(same(r.readbackAccumulator(), o.render(first, spp))))
         if not all(checks):
             bad.append([seed, checks])   # [constants, primary hits, per-bounce hit ids, per-sample radiance, accumulator]
     r.close()
-    print(json.dumps({"first": first, "count": count, "mismatching_seeds": bad, "seconds": round(time.time() - t0, 1)}))
+    print(json.dumps({"first": seed0, "extras": extras, "count": count, "mismatching_seeds": bad, "seconds": round(time.time() - t0, 1)}))
 
 
 if __name__ == "__main__":

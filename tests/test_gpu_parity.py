@@ -35,8 +35,11 @@ def _scene(name):
 
 def _start(r, scene, w, h, spp, bounces, integrator=abi.INTEGRATOR_MIS, **kw):
     r.selectKernel(integrator)
-    r.startRender(scene, (w, h), spp, max_bounces=bounces, **kw)
-    return make_params(w, h, spp, bounces, integrator=integrator)
+    kw = dict(kw)
+    space = kw.pop("working_space", scenes.BT2020)
+    r.startRender(scene, (w, h), spp, workingSpace=space, max_bounces=bounces, **kw)
+    # (the oracle's parameters: what changes the arithmetic; first_sample is passed to OracleScene.render by the caller)
+    return make_params(w, h, spp, bounces, flags=kw.get("flags", abi.FLAG_MULTISCATTER_GGX), integrator=integrator, working_space=space)
 
 
 @pytest.mark.parametrize("name", ["cornell", "cornell_default_cam", "cornell_sphere", "field8"])
@@ -715,13 +718,17 @@ def test_radix_tree_fallback_builder_gives_the_same_image(gpu_renderer):
     assert a.tobytes() == oracle_lib.OracleScene(sc, p).render(0, 2).tobytes()
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(24)) + [1000 + i for i in range(12)])
 def test_random_scene_fuzz_parity(gpu_renderer, seed):
-    """24 seeded random scenes (scenes.random_scene) through the HIP path against the oracle: hit ids, per-sample radiance and
-    the accumulated image, bit for bit (NaNs — the reference's BSDF produces a few — only have to coincide)."""
-    sc = scenes.random_scene(seed)
+    """36 seeded random scenes (scenes.random_scene) through the HIP path against the oracle: hit ids, per-sample radiance and
+    the accumulated image, bit for bit (NaNs — the reference's BSDF produces a few — only have to coincide).  Seeds >= 1000 draw the
+    `extras` too (every texture slot, anisotropy rotation, degenerate material corners) and switch the multiscatter flag / working space.
+    (tests/fuzz_parity_sweep.py is the same check over thousands of seeds: r03 ran 3 000 plain + 3 000 with extras, all identical.)"""
+    extras = seed >= 1000
+    sc = scenes.random_scene(seed, extras=extras)
     integ = abi.INTEGRATOR_MIS if seed % 4 else abi.INTEGRATOR_SIMPLE
-    p = _start(gpu_renderer, sc, 96, 54, 2, 6, integrator=integ)
+    kw = dict(flags=abi.FLAG_MULTISCATTER_GGX if seed % 5 else 0, working_space=scenes.BT2020 if seed % 3 else scenes.BT709) if extras else {}
+    p = _start(gpu_renderer, sc, 96, 54, 2, 6, integrator=integ, **kw)
     o = oracle_lib.OracleScene(sc, p)
     assert bytes(gpu_renderer.constants()) == bytes(o.constants())
     assert gpu_renderer.tracePrimary(1).tobytes() == o.trace_primary(1).tobytes()
