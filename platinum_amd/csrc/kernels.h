@@ -16,6 +16,7 @@ struct WaveStats { unsigned long long closest, shadow, shaded, paths; };  // per
 struct Segments {
   uint32_t* active[2];  // [state buffer][segment] live paths in the segment
   uint32_t* shadow;     // [segment] shadow rays in the segment
+  uint32_t* poison;     // [segment] != 0: a path of the segment carries a throughput that is not finite (k_shade's scan of the misses)
   WaveStats* stats;     // [nstats] per physical wave of the producer kernels
   uint32_t* table_closest;  // dense lists of non-empty chunks, (k << 16) | segment, rebuilt by k_chunk_tables
   uint32_t* table_shadow;

@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DeviceScene S, PathState st, 
       }
       n_out += (uint32_t)__popcll(m);
     }
-    if (lane == 0) seg.active[0][sg] = n_out;
+    if (lane == 0) { seg.active[0][sg] = n_out; seg.poison[sg] = 0u; }
     started += n_out;
   }
   if (lane == 0) {
@@ -466,6 +466,9 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
     const uint32_t lbuf_base = segment_lbuf_base(seg, sg);  // this segment's window of the per-sample radiance buffer
     const uint32_t n = __builtin_amdgcn_readfirstlane(seg.active[cur][sg]);  // (a scalar for the compiler too: the scan loop and the bin counters stay in SGPRs)
     uint32_t n_out = 0, n_shadow = 0;
+    // != 0: a path of this segment (paths never leave their segment) carries a throughput with an infinity or a NaN in it
+    const uint32_t seg_poisoned = S.env_texture < 0 ? __builtin_amdgcn_readfirstlane(seg.poison[sg]) : 0u;
+    unsigned long long poisoned_now = 0;
     // ---- hits are shaded one MATERIAL CLASS per wave pass.  The segment is scanned 64 slots at a time; every slot number goes
     //      to the LDS bin of its hit's class (4 lobe classes + misses); as soon as a bin holds 64 entries they are shaded
     //      together; what is left at the end of the segment is shaded in mixed passes.  (Measured on C3: the same kernel costs
@@ -482,9 +485,13 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
           cls = w == kInvalidRef ? 4u : (w >> 28) & 3u;
           // a miss without an environment adds attenuation * backgroundColor = attenuation * 0 (kernel.metal:311 / :541, defs.metal:21):
           // nothing — unless the BSDF has driven the throughput to an infinity or a NaN (a zero pdf), when the reference's sum turns NaN
+          // (one in ~1e8 paths: the segment's flag says whether the throughputs of its misses have to be looked at at all)
           if (w == kInvalidRef && S.env_texture < 0) {
-            const vec4 a4 = sin.att[seg_slot(seg.nseg, sg, k)];
-            if (!att_poisoned(v3(a4.x, a4.y, a4.z))) cls = 5u;
+            if (!seg_poisoned) cls = 5u;
+            else {
+              const vec4 a4 = sin.att[seg_slot(seg.nseg, sg, k)];
+              if (!att_poisoned(v3(a4.x, a4.y, a4.z))) cls = 5u;
+            }
           }
         }
         const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3),
@@ -589,6 +596,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
           Lbuf[pid] = L;
         }
         const unsigned long long m = __ballot(bo.alive);
+        poisoned_now |= __ballot(bo.alive && att_poisoned(bo.next_att));
         if (bo.alive) {
           const uint32_t j = seg_slot(seg.nseg, sg, n_out + wave_prefix(m));
           st_stream(&sout.rayO[j], vec4{g.hitPos.x, g.hitPos.y, g.hitPos.z, bo.next_pdf});
@@ -609,6 +617,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
     if (lane == 0) {
       seg.active[cur ^ 1][sg] = n_out;
       seg.shadow[sg] = n_shadow;
+      if (poisoned_now) seg.poison[sg] = 1u;
     }
     total_out += n_out;
     total_shadow += n_shadow;

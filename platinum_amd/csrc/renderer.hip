@@ -437,6 +437,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   PT_HIP(r->Lbuf.alloc((size_t)((p->width + 7) / 8) * ((p->height + 7) / 8) * 64 * sif));  // tile-major, whole tiles (kernels.hip lbuf_index)
   for (int k = 0; k < 2; k++) PT_HIP(r->seg_active[k].alloc(r->nseg));
   PT_HIP(r->seg_shadow.alloc(r->nseg));
+  PT_HIP(r->seg_poison.alloc(r->nseg));
   PT_HIP(r->wave_stats.alloc(r->nstats));
   for (int k = 0; k < 2; k++) PT_HIP(r->chunk_table[k].alloc(r->capacity / 64));
   PT_HIP(r->spill.alloc((size_t)r->trace_grid * trace_block_threads(r->two_level) * kSpillStack));  // per-thread HBM stack slab behind the LDS stack

@@ -110,7 +110,7 @@ struct pt_renderer {
   uint32_t samples_in_flight = 0;
   size_t capacity = 0;  // path slots
   DevBuf<vec4> st_rayO[2], st_rayD[2], st_att[2], hit, sq_o, sq_d, sq_c, Lbuf, acc_own;
-  DevBuf<uint32_t> spill, seg_active[2], seg_shadow;
+  DevBuf<uint32_t> spill, seg_active[2], seg_shadow, seg_poison;
   DevBuf<WaveStats> wave_stats;
   DevBuf<uint32_t> chunk_table[2];
   DevBuf<vec4> gmon_buckets_d;  // [bucket][pixel] with PT_FLAG_GMON (renderer_pt.cpp:824-830)
@@ -151,7 +151,7 @@ struct pt_renderer {
 
   PathState path_state(int k) { return PathState{st_rayO[k].p, st_rayD[k].p, st_att[k].p}; }
   ShadowQueue shadow_queue() { return ShadowQueue{sq_o.p, sq_d.p, sq_c.p}; }
-  Segments segments() { return Segments{{seg_active[0].p, seg_active[1].p}, seg_shadow.p, wave_stats.p, chunk_table[0].p, chunk_table[1].p, seg_cap, nseg, tiles_per_seg, /*nsamples: set per batch*/ 0u, seg_bands, nstats, refill_threshold}; }
+  Segments segments() { return Segments{{seg_active[0].p, seg_active[1].p}, seg_shadow.p, seg_poison.p, wave_stats.p, chunk_table[0].p, chunk_table[1].p, seg_cap, nseg, tiles_per_seg, /*nsamples: set per batch*/ 0u, seg_bands, nstats, refill_threshold}; }
 
   // A restart keeps every device array (they are re-filled, and only re-allocated when they must grow); what it drops is the
   // acceleration structure of the previous scene and the "started" state.  release_all() returns the memory (pt_destroy).
@@ -175,7 +175,7 @@ struct pt_renderer {
     materials.release(); lights_d.release(); tex_pixels.release(); textures.release(); env_alias_d.release(); scene_d.release(); shade_recs.release(); light_recs.release(); light_cdf.release();
     inst_trav.release();
     for (int k = 0; k < 2; k++) { st_rayO[k].release(); st_rayD[k].release(); st_att[k].release(); }
-    seg_active[0].release(); seg_active[1].release(); seg_shadow.release(); wave_stats.release(); chunk_table[0].release(); chunk_table[1].release(); gmon_buckets_d.release(); render_target.release();
+    seg_active[0].release(); seg_active[1].release(); seg_shadow.release(); seg_poison.release(); wave_stats.release(); chunk_table[0].release(); chunk_table[1].release(); gmon_buckets_d.release(); render_target.release();
     hit.release(); sq_o.release(); sq_d.release(); sq_c.release(); Lbuf.release(); acc_own.release(); spill.release();
   }
   void drop_timed() {
