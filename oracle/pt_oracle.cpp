@@ -16,6 +16,8 @@
 // eight tables (tests/test_lut_pin.py, tools/lut_pin.py: agreement to ~3e-4).
 // Ray/triangle intersection and texture filtering are Apple-closed in the reference and are DEFINED
 // here: => "parity unpinned" for hit selection, LUT interpolation rounding and the float radiance.
+// (Round 3: tests/test_gpu_physics.py anchors the integrator as a whole in physics — analytic irradiance under a panel light to 0.3 %, white
+// furnace, MIS against SIMPLE — through the HIP path, which is bit-identical to this file on every small case.  A bound, not a reference pin.)
 //
 // Intersection contract (ours): triangles are flattened to world space in fp32 (transformPoint below), tested
 // with the Moeller-Trumbore sequence in intersect_triangle(); closest hit = minimum t in [tmin, tmax], ties
