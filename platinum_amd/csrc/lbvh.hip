@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+
 #include "kernels.h"
 #include "pt_shade.h"
 
@@ -67,7 +68,9 @@ __global__ void k_init_bounds(int* bounds) {
   else if (threadIdx.x < 6) bounds[threadIdx.x] = (int)0x80000000;
 }
 
+// (grid <= 256 blocks, one set of atomics per BLOCK: with one per wave of 1 024 blocks the 24 k same-address atomics took 280 us of a 2.5 ms build)
 __global__ void __launch_bounds__(256) k_bounds(const Box* __restrict__ boxes, uint32_t n, int* __restrict__ bounds) {
+  __shared__ float red[6][4];
   float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
   for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < n; g += gridDim.x * 256) {
     const Box b = boxes[g];
@@ -83,10 +86,15 @@ __global__ void __launch_bounds__(256) k_bounds(const Box* __restrict__ boxes, u
       hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
     }
   if ((threadIdx.x & 63) == 0)
-    for (int k = 0; k < 3; k++) {
-      atomicMin(&bounds[k], float_to_ordered(lo[k]));
-      atomicMax(&bounds[3 + k], float_to_ordered(hi[k]));
-    }
+    for (int k = 0; k < 3; k++) { red[k][threadIdx.x >> 6] = lo[k]; red[3 + k][threadIdx.x >> 6] = hi[k]; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    atomicMin(&bounds[k], float_to_ordered(fminf(fminf(red[k][0], red[k][1]), fminf(red[k][2], red[k][3]))));
+  } else if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    atomicMax(&bounds[k], float_to_ordered(fmaxf(fmaxf(red[k][0], red[k][1]), fmaxf(red[k][2], red[k][3]))));
+  }
 }
 
 __device__ __forceinline__ uint64_t expand21(uint64_t v) {  // spread 21 bits to every third bit
@@ -250,13 +258,11 @@ __global__ void __launch_bounds__(256) k_emit(int n, const uint2* __restrict__ c
 // the dense index next_base + its position in the next level's queue.  The 4-wide tree therefore occupies node_count
 // consecutive 64-byte records with the top levels first (C3: 506 175 nodes = 32 MB instead of the 66 MB of n - 1 slots, and a
 // small tree can be copied into LDS as it stands).  Leaf refs: leaf_tag | (remap ? order[sorted position] : sorted position).
-__global__ void __launch_bounds__(256) k_emit_sah(uint32_t n_in, const uint2* __restrict__ q_in, uint2* __restrict__ q_out,
-                                                   uint32_t* __restrict__ n_out, uint32_t next_base, uint32_t ref_base, uint32_t leaf_tag,
-                                                   uint32_t remap, const uint2* __restrict__ children, const Box* __restrict__ leaf_boxes,
-                                                   const uint32_t* __restrict__ order, const Box* __restrict__ node_boxes,
-                                                   BvhNode* __restrict__ nodes) {
-  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= n_in) return;
+__device__ __forceinline__ void emit_sah_node(uint32_t t, const uint2* __restrict__ q_in, uint2* __restrict__ q_out,
+                                              uint32_t* __restrict__ n_out, uint32_t next_base, uint32_t ref_base, uint32_t leaf_tag,
+                                              uint32_t remap, const uint2* __restrict__ children, const Box* __restrict__ leaf_boxes,
+                                              const uint32_t* __restrict__ order, const Box* __restrict__ node_boxes,
+                                              BvhNode* __restrict__ nodes) {
   const uint32_t i = q_in[t].x, dense = q_in[t].y;
   auto box_of = [&](uint32_t ref) { return (ref & kLeafBit) ? leaf_boxes[order[ref & ~kLeafBit]] : node_boxes[ref]; };
   auto half_area = [](const Box& b) {
@@ -300,6 +306,41 @@ __global__ void __launch_bounds__(256) k_emit_sah(uint32_t n_in, const uint2* __
   }
   nodes[dense] = quantize_node4(boxes, refs, count);
 }
+__global__ void __launch_bounds__(256) k_emit_sah(uint32_t n_in, const uint2* __restrict__ q_in, uint2* __restrict__ q_out,
+                                                   uint32_t* __restrict__ n_out, uint32_t next_base, uint32_t ref_base, uint32_t leaf_tag,
+                                                   uint32_t remap, const uint2* __restrict__ children, const Box* __restrict__ leaf_boxes,
+                                                   const uint32_t* __restrict__ order, const Box* __restrict__ node_boxes,
+                                                   BvhNode* __restrict__ nodes) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_in) return;
+  emit_sah_node(t, q_in, q_out, n_out, next_base, ref_base, leaf_tag, remap, children, leaf_boxes, order, node_boxes, nodes);
+}
+
+// ---- the builder's device-resident state: PLOC passes and collapse levels are launched back to back, each kernel reads what the one
+// before it left here, and the host looks in only every few passes / levels (it used to wait for a read-back after EVERY pass and level:
+// 46 round trips of ~25 us on C3, a third of the build).  Grids are sized from the last count the host saw (counts only shrink during
+// PLOC; a collapse level is at most 4x the one before); threads beyond the real count leave at once.
+// (Measured and dropped, r3: the same loops as two COOPERATIVE kernels with grid barriers — correct, and 3.5x slower: a grid-wide
+// barrier costs ~100 us on this part, it has to write back and invalidate eight XCD-private L2s; tools/experiments/r03_bvh_cooperative_build.patch.)
+constexpr uint32_t kMaxLevels = 128;  // 4-wide levels (the traversal stack bounds them far lower: 3 entries per level)
+struct PlocSlot { uint32_t cur, base, buf, ok; };  // clusters left, binary nodes created, which cluster buffer holds them, 0 = gave up
+struct BuildState {
+  PlocSlot ploc[2];                  // pass p reads slot p & 1 and writes slot (p + 1) & 1
+  uint32_t level_count[kMaxLevels];  // collapse: nodes queued for level l + 1 by level l (zeroed before the first level)
+};
+
+// One collapse level, its size and numbering base read from the counts the levels before it left (level 0: the root alone).
+__global__ void __launch_bounds__(256) k_emit_sah_dev(const BuildState* st, uint32_t ploc_slot, uint32_t level, const uint2* __restrict__ q_in,
+                                                       uint2* __restrict__ q_out, uint32_t* level_count, uint32_t ref_base, uint32_t leaf_tag,
+                                                       uint32_t remap, const uint2* __restrict__ children, const Box* __restrict__ leaf_boxes,
+                                                       const uint32_t* __restrict__ order, const Box* __restrict__ node_boxes, BvhNode* __restrict__ nodes) {
+  if (st->ploc[ploc_slot].ok == 0) return;  // PLOC gave up: the host falls back to the radix tree
+  uint32_t n_in = 1, before = 0;            // nodes of this level, nodes of all levels before it
+  for (uint32_t l = 0; l < level; l++) { before += n_in; n_in = st->level_count[l]; }
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_in) return;
+  emit_sah_node(t, q_in, q_out, &level_count[level], before + n_in, ref_base, leaf_tag, remap, children, leaf_boxes, order, node_boxes, nodes);
+}
 __global__ void __launch_bounds__(256) k_reorder_tris(int n, const uint32_t* __restrict__ order, const TriRec* __restrict__ tris_in,
                                                        TriRec* __restrict__ tris_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -317,6 +358,7 @@ __global__ void k_seed_queue(uint2* q, uint32_t* counters, uint32_t root) { q[0]
 #define PT_PLOC_RADIUS 8
 #endif
 constexpr int kPlocRadius = PT_PLOC_RADIUS;
+constexpr uint32_t kPlocTail = 1024;  // clusters the single-block tail takes over at (k_ploc_tail)
 __device__ __forceinline__ float merged_half_area(const Box& a, const Box& b) {
   const float x = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]);
   const float y = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]);
@@ -381,14 +423,152 @@ __global__ void __launch_bounds__(256) k_ploc_apply(uint32_t n, const uint32_t* 
   }
 }
 
+// One PLOC pass as three launches that take the cluster count from device memory: (A) nearest-neighbour search; (B) every block counts the
+// merges / survivors of its contiguous tile of the cluster array; (C) every block sums the counts of the blocks before it (its output
+// offsets), recomputes its tile's flags, numbers them with ballots, writes the merged / kept clusters, and block 0 leaves the next pass its
+// state.  Same candidate order, same mutual-pair rule, same numbering (positions and node indices in cluster order) as k_ploc_nn / _flags /
+// two device-wide prefix sums / _apply: the tree is the same; a pass is 3 launches instead of 7 + a read-back.  Passes launched after the
+// cluster count has fallen to kPlocTail (the host's count is a few passes old) do nothing but hand the state on.
+__device__ __forceinline__ void ploc_flags(uint32_t i, uint32_t cur, const uint32_t* __restrict__ nn, uint32_t& j, bool& mf, bool& kf) {
+  j = i; mf = false; kf = false;
+  if (i < cur) {
+    j = nn[i];
+    const bool mutual = j != i && nn[j] == i;
+    mf = mutual && i < j;
+    kf = !(mutual && i > j);
+  }
+}
+__device__ __forceinline__ bool ploc_active(const PlocSlot& ps) { return ps.ok != 0 && ps.cur > kPlocTail; }
+__global__ void k_ploc_state_init(BuildState* st, uint32_t n) {
+  st->ploc[0] = PlocSlot{n, 0u, 0u, 1u};
+  st->ploc[1] = PlocSlot{n, 0u, 0u, 1u};
+}
+__global__ void __launch_bounds__(256) k_ploc_nn_dev(const BuildState* __restrict__ st, uint32_t pass, const Box* __restrict__ box0, const Box* __restrict__ box1,
+                                                      uint32_t* __restrict__ nn) {
+  const PlocSlot ps = st->ploc[pass & 1u];
+  if (!ploc_active(ps)) return;
+  const Box* cl_box = ps.buf ? box1 : box0;
+  const uint32_t cur = ps.cur;
+  for (uint32_t ii = blockIdx.x * 256 + threadIdx.x; ii < cur; ii += gridDim.x * 256) {
+    const int i = (int)ii;
+    const Box me = cl_box[i];
+    float best = kInf;
+    int bj = i;
+    auto consider = [&](int j) {
+      if (j < 0 || j >= (int)cur || j == i) return;
+      const float ar = merged_half_area(me, cl_box[j]);
+      if (ar < best) { best = ar; bj = j; }
+    };
+    consider(i ^ 1);
+    for (int d = 1; d <= kPlocRadius; d++) { consider(i - d); consider(i + d); }
+    nn[i] = (uint32_t)bj;
+  }
+}
+// this block's tile [t0, t1) of the cluster array: a multiple of the block size per block, in cluster order
+__device__ __forceinline__ void ploc_tile(uint32_t cur, uint32_t& t0, uint32_t& t1) {
+  const uint32_t tile = ((cur + gridDim.x - 1) / gridDim.x + 255u) & ~255u;
+  t0 = min(cur, blockIdx.x * tile);
+  t1 = min(cur, t0 + tile);
+}
+__global__ void __launch_bounds__(256) k_ploc_count_dev(const BuildState* __restrict__ st, uint32_t pass, const uint32_t* __restrict__ nn,
+                                                         uint2* __restrict__ block_counts) {
+  __shared__ uint32_t s_m[4], s_k[4];
+  const PlocSlot ps = st->ploc[pass & 1u];
+  if (!ploc_active(ps)) return;
+  uint32_t t0, t1;
+  ploc_tile(ps.cur, t0, t1);
+  uint32_t cm = 0, ck = 0;
+  for (uint32_t c = t0; c < t1; c += 256) {
+    uint32_t j; bool mf, kf;
+    ploc_flags(c + threadIdx.x, ps.cur, nn, j, mf, kf);
+    cm += (uint32_t)__popcll(__ballot(mf)); ck += (uint32_t)__popcll(__ballot(kf));
+  }
+  if ((threadIdx.x & 63u) == 0) { s_m[threadIdx.x >> 6] = cm; s_k[threadIdx.x >> 6] = ck; }
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = make_uint2(s_m[0] + s_m[1] + s_m[2] + s_m[3], s_k[0] + s_k[1] + s_k[2] + s_k[3]);
+}
+__global__ void __launch_bounds__(256) k_ploc_apply_dev(BuildState* __restrict__ st, uint32_t pass, uint32_t n, const uint32_t* __restrict__ nn,
+                                                         const uint2* __restrict__ block_counts, uint32_t* __restrict__ ref0, uint32_t* __restrict__ ref1,
+                                                         Box* __restrict__ box0, Box* __restrict__ box1, uint2* __restrict__ children,
+                                                         Box* __restrict__ node_boxes) {
+  __shared__ uint32_t s_m[4], s_k[4];
+  __shared__ uint32_t s_red[4][256];
+  const PlocSlot ps = st->ploc[pass & 1u];
+  if (!ploc_active(ps)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->ploc[(pass + 1u) & 1u] = ps;
+    return;
+  }
+  const uint32_t cur = ps.cur, base = ps.base;
+  const uint32_t* cl_ref = ps.buf ? ref1 : ref0; const Box* cl_box = ps.buf ? box1 : box0;
+  uint32_t* out_ref = ps.buf ? ref0 : ref1; Box* out_box = ps.buf ? box0 : box1;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  // offsets of this block = counts of the blocks before it; totals = counts of all blocks
+  uint32_t off_m, off_k, tot_m, tot_k;
+  {
+    uint32_t pm = 0, pk = 0, am = 0, ak = 0;
+    for (uint32_t b = threadIdx.x; b < gridDim.x; b += 256) {
+      const uint2 v = block_counts[b];
+      am += v.x; ak += v.y;
+      if (b < blockIdx.x) { pm += v.x; pk += v.y; }
+    }
+    s_red[0][threadIdx.x] = pm; s_red[1][threadIdx.x] = pk; s_red[2][threadIdx.x] = am; s_red[3][threadIdx.x] = ak;
+    __syncthreads();
+    for (uint32_t o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o)
+        for (int q = 0; q < 4; q++) s_red[q][threadIdx.x] += s_red[q][threadIdx.x + o];
+      __syncthreads();
+    }
+    off_m = s_red[0][0]; off_k = s_red[1][0]; tot_m = s_red[2][0]; tot_k = s_red[3][0];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // no progress / inconsistent counts: give up (the host falls back to the radix tree)
+    const bool good = tot_m != 0 && tot_k == cur - tot_m && base + tot_m <= n - 1;
+    st->ploc[(pass + 1u) & 1u] = PlocSlot{tot_k, base + tot_m, ps.buf ^ 1u, good ? 1u : 0u};
+  }
+  uint32_t t0, t1;
+  ploc_tile(cur, t0, t1);
+  for (uint32_t c = t0; c < t1; c += 256) {
+    const uint32_t i = c + threadIdx.x;
+    uint32_t j; bool mf, kf;
+    ploc_flags(i, cur, nn, j, mf, kf);
+    const unsigned long long bm = __ballot(mf), bk = __ballot(kf);
+    if (lane == 0) { s_m[wave] = (uint32_t)__popcll(bm); s_k[wave] = (uint32_t)__popcll(bk); }
+    __syncthreads();
+    uint32_t wm = 0, wk = 0;  // counts of the waves before this one in the chunk
+    for (uint32_t w = 0; w < wave; w++) { wm += s_m[w]; wk += s_k[w]; }
+    const uint32_t cm = s_m[0] + s_m[1] + s_m[2] + s_m[3], ck = s_k[0] + s_k[1] + s_k[2] + s_k[3];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (kf) {
+      const uint32_t pos = off_k + wk + (uint32_t)__popcll(bk & below);
+      if (mf) {
+        const uint32_t idx = base + off_m + wm + (uint32_t)__popcll(bm & below);
+        const Box x = cl_box[i], y = cl_box[j];
+        Box m;
+        for (int k = 0; k < 3; k++) { m.lo[k] = fminf(x.lo[k], y.lo[k]); m.hi[k] = fmaxf(x.hi[k], y.hi[k]); }
+        m._pad[0] = m._pad[1] = 0.0f;
+        if (idx < n - 1) {  // (always, when the counts are consistent; an inconsistent pass is abandoned above)
+          children[idx] = make_uint2(cl_ref[i], cl_ref[j]);
+          node_boxes[idx] = m;
+        }
+        out_ref[pos] = idx;
+        out_box[pos] = m;
+      } else {
+        out_ref[pos] = cl_ref[i];
+        out_box[pos] = cl_box[i];
+      }
+    }
+    off_m += cm; off_k += ck;
+    __syncthreads();
+  }
+}
+
 // The LAST passes of PLOC in one launch: once at most kPlocTail clusters are left, one 1024-thread block keeps them in LDS and
 // runs nearest-neighbour search, mutual-pair test, the two prefix sums and the merge for every remaining pass between block
 // barriers.  Same arithmetic, same candidate order, same node numbering as the multi-kernel passes (k_ploc_nn / _flags / _apply):
 // the tree does not change; what goes away is ~25 of the ~40 passes' worth of tiny dependent launches and host round trips
 // (C3: BVH build 4.4 -> 3.x ms).  counts[0] = nodes created in all (base), counts[1] = clusters left (1 on success).
-constexpr uint32_t kPlocTail = 1024;
-__global__ void __launch_bounds__(1024) k_ploc_tail(uint32_t n0, uint32_t base0, const uint32_t* __restrict__ ref_in, const Box* __restrict__ box_in,
-                                                     uint2* __restrict__ children, Box* __restrict__ node_boxes, uint32_t* __restrict__ counts) {
+__device__ __forceinline__ void ploc_tail_body(uint32_t n0, uint32_t base0, const uint32_t* __restrict__ ref_in, const Box* __restrict__ box_in,
+                                               uint2* __restrict__ children, Box* __restrict__ node_boxes, uint32_t* __restrict__ counts) {
   __shared__ Box s_box[2][kPlocTail];
   __shared__ uint32_t s_ref[2][kPlocTail];
   __shared__ uint32_t s_nn[kPlocTail];
@@ -456,6 +636,22 @@ __global__ void __launch_bounds__(1024) k_ploc_tail(uint32_t n0, uint32_t base0,
     a ^= 1;
   }
   if (i == 0) { counts[0] = base; counts[1] = cur; }
+}
+__global__ void __launch_bounds__(1024) k_ploc_tail(uint32_t n0, uint32_t base0, const uint32_t* __restrict__ ref_in, const Box* __restrict__ box_in,
+                                                     uint2* __restrict__ children, Box* __restrict__ node_boxes, uint32_t* __restrict__ counts) {
+  ploc_tail_body(n0, base0, ref_in, box_in, children, node_boxes, counts);
+}
+// ... the same, entered from the device-driven passes: cluster count, node base and buffer come from the state slot; it leaves its
+// verdict there (ok = the root is the last node created, n - 2, and one cluster is left)
+__global__ void __launch_bounds__(1024) k_ploc_tail_dev(BuildState* __restrict__ st, uint32_t slot, uint32_t n, const uint32_t* __restrict__ ref0,
+                                                         const uint32_t* __restrict__ ref1, const Box* __restrict__ box0, const Box* __restrict__ box1,
+                                                         uint2* __restrict__ children, Box* __restrict__ node_boxes, uint32_t* __restrict__ counts) {
+  const PlocSlot ps = st->ploc[slot];
+  if (ps.ok == 0) return;
+  if (ps.cur > kPlocTail) { if (threadIdx.x == 0) st->ploc[slot].ok = 0; return; }
+  ploc_tail_body(ps.cur, ps.base, ps.buf ? ref1 : ref0, ps.buf ? box1 : box0, children, node_boxes, counts);
+  __syncthreads();
+  if (threadIdx.x == 0) st->ploc[slot] = PlocSlot{counts[1], counts[0], ps.buf, (counts[0] == n - 1 && counts[1] == 1) ? 1u : 0u};
 }
 
 #define LB_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = e_; goto done; } } while (0)
@@ -535,6 +731,80 @@ done:
 }
 
 
+// The device-driven build: PLOC passes, PLOC tail and collapse levels launched back to back (kernels above); the host reads the state
+// every kSyncPasses passes / kSyncLevels levels.  PTAMD_BVH_LEGACY=1 selects the per-pass / per-level launches (the fallback, kept for A/B).
+constexpr uint32_t kSyncPasses = 4, kSyncLevels = 6, kPlocBlocks = 1024;
+static bool device_driven_build() { static const bool on = getenv("PTAMD_BVH_LEGACY") == nullptr; return on; }
+static size_t dev_scratch_bytes(uint32_t n) {
+  return 2 * (Arena::pad(sizeof(uint32_t) * (size_t)n) + Arena::pad(sizeof(Box) * (size_t)n)) + Arena::pad(sizeof(uint32_t) * (size_t)n) +
+         Arena::pad(sizeof(uint2) * (size_t)kPlocBlocks) + Arena::pad(2 * sizeof(uint32_t)) + Arena::pad(sizeof(BuildState));
+}
+// children[] / node_boxes[] / nodes_out are filled on success (*ok): *emitted 4-wide nodes in *levels levels, root = dense node 0.
+static hipError_t build_dev(hipStream_t s, uint32_t n, const Box* leaf_boxes, const uint32_t* order, uint32_t stack_capacity, uint2* children,
+                            Box* node_boxes, uint2* q0, uint2* q1, uint32_t ref_base, uint32_t leaf_tag, uint32_t remap, BvhNode* nodes_out,
+                            Arena& arena, bool* ok, uint32_t* emitted, uint32_t* levels) {
+  hipError_t err = hipSuccess;
+  *ok = false;
+  const size_t mark = arena.off;
+  uint32_t* ref0 = arena.take<uint32_t>(n); Box* box0 = arena.take<Box>(n);
+  uint32_t* ref1 = arena.take<uint32_t>(n); Box* box1 = arena.take<Box>(n);
+  uint32_t* nn = arena.take<uint32_t>(n);
+  uint2* block_counts = arena.take<uint2>(kPlocBlocks);
+  uint32_t* counts = arena.take<uint32_t>(2);
+  BuildState* st = arena.take<BuildState>(1);
+  BuildState h;
+  uint32_t pass = 0, bound = n, level = 0, level_bound = 1, done_levels = 0, total = 0;
+  bool finished = false;
+  if (!st) { arena.off = mark; return hipErrorOutOfMemory; }
+  LB_CHECK(hipMemsetAsync(st, 0, sizeof(BuildState), s));
+  hipLaunchKernelGGL(k_ploc_state_init, dim3(1), dim3(1), 0, s, st, n);
+  hipLaunchKernelGGL(k_ploc_init, dim3((n + 255) / 256), dim3(256), 0, s, n, leaf_boxes, order, ref0, box0);
+  // ---- PLOC passes down to kPlocTail clusters ----
+  while (bound > kPlocTail) {
+    if (pass > 256) goto done;  // >= 1 merge per pass is guaranteed, ~30 % per pass is typical: a degenerate input (-> radix tree)
+    const uint32_t blocks = (bound + 255) / 256;
+    const uint32_t tiles = blocks < kPlocBlocks ? blocks : kPlocBlocks;
+    for (uint32_t k = 0; k < kSyncPasses; k++, pass++) {
+      hipLaunchKernelGGL(k_ploc_nn_dev, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, s, st, pass, box0, box1, nn);
+      hipLaunchKernelGGL(k_ploc_count_dev, dim3(tiles), dim3(256), 0, s, st, pass, nn, block_counts);
+      hipLaunchKernelGGL(k_ploc_apply_dev, dim3(tiles), dim3(256), 0, s, st, pass, n, nn, block_counts, ref0, ref1, box0, box1, children, node_boxes);
+    }
+    LB_CHECK(hipMemcpyAsync(&h.ploc[0], &st->ploc[pass & 1u], sizeof(PlocSlot), hipMemcpyDeviceToHost, s));
+    LB_CHECK(hipStreamSynchronize(s));
+    if (!h.ploc[0].ok || h.ploc[0].cur > bound) goto done;
+    bound = h.ploc[0].cur;
+  }
+  hipLaunchKernelGGL(k_ploc_tail_dev, dim3(1), dim3(1024), 0, s, st, pass & 1u, n, ref0, ref1, box0, box1, children, node_boxes, counts);
+  // ---- level-synchronous SAH collapse; the root is the last binary node created ----
+  hipLaunchKernelGGL(k_seed_queue, dim3(1), dim3(1), 0, s, q0, counts, n - 2);
+  while (!finished) {
+    for (uint32_t k = 0; k < kSyncLevels; k++, level++) {
+      if ((level + 1) * 3 > stack_capacity || level + 1 >= kMaxLevels) break;  // (whether the tree really is this deep shows below)
+      hipLaunchKernelGGL(k_emit_sah_dev, dim3((level_bound + 255) / 256), dim3(256), 0, s, st, pass & 1u, level, (level & 1u) ? q1 : q0, (level & 1u) ? q0 : q1,
+                         st->level_count, ref_base, leaf_tag, remap, children, leaf_boxes, order, node_boxes, nodes_out);
+      level_bound = level_bound > n / 4 ? n : level_bound * 4;
+    }
+    LB_CHECK(hipMemcpyAsync(&h, st, sizeof(BuildState), hipMemcpyDeviceToHost, s));
+    LB_CHECK(hipStreamSynchronize(s));
+    if (!h.ploc[pass & 1u].ok) goto done;
+    // levels done so far: level l exists when l == 0 or level l - 1 queued something for it
+    total = 0; done_levels = 0;
+    for (uint32_t l = 0, n_in = 1; l < level && n_in > 0; l++) { total += n_in; done_levels = l + 1; n_in = h.level_count[l]; finished = n_in == 0; }
+    if (!finished) {
+      if ((level + 1) * 3 > stack_capacity || level + 1 >= kMaxLevels) goto done;  // deeper than the traversal stack: the caller falls back
+      level_bound = std::min<uint64_t>((uint64_t)h.level_count[level - 1], (uint64_t)n);  // the next level's real size
+    }
+  }
+  if (total >= 1 && total <= n - 1) {
+    *ok = true;
+    *emitted = total;
+    *levels = done_levels;
+  }
+done:
+  arena.off = mark;
+  return err;
+}
+
 // ---- one tree ------------------------------------------------------------------------------------------------------------
 struct TreeInfo { uint32_t root_ref = kInvalidRef, node_span = 0, depth4 = 0; };
 
@@ -568,7 +838,8 @@ static hipError_t build_tree(hipStream_t s, uint32_t n, const Box* leaf_boxes, u
     const size_t N = n;
     arena.cap = Arena::pad(sizeof(int) * 8) + Arena::pad(4 * sizeof(uint32_t)) + 2 * Arena::pad(sizeof(uint64_t) * N) + 2 * Arena::pad(sizeof(uint32_t) * N) +
                 Arena::pad(sizeof(uint2) * (N - 1)) + Arena::pad(sizeof(uint32_t) * (N - 1)) + Arena::pad(sizeof(uint32_t) * N) + Arena::pad(sizeof(uint32_t) * (N - 1)) +
-                Arena::pad(sizeof(Box) * (N - 1)) + 2 * Arena::pad(sizeof(uint2) * N) + Arena::pad(sort_bytes) + ploc_scratch_bytes(n, &scan_bytes);
+                Arena::pad(sizeof(Box) * (N - 1)) + 2 * Arena::pad(sizeof(uint2) * N) + Arena::pad(sort_bytes) +
+                std::max(ploc_scratch_bytes(n, &scan_bytes), dev_scratch_bytes(n));
     LB_CHECK(hipMalloc((void**)&arena.base, arena.cap));
   }
   bounds = arena.take<int>(8);
@@ -585,11 +856,29 @@ static hipError_t build_tree(hipStream_t s, uint32_t n, const Box* leaf_boxes, u
   sort_tmp = arena.take<char>(sort_bytes);
 
   hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, s, bounds);
-  hipLaunchKernelGGL(k_bounds, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, s, leaf_boxes, n, bounds);
+  hipLaunchKernelGGL(k_bounds, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, s, leaf_boxes, n, bounds);
   hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(256), 0, s, leaf_boxes, n, bounds, keys_a, vals_a);
   LB_CHECK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 63, s));
 
   for (;;) {
+    if (use_ploc && device_driven_build()) {
+      // PLOC + collapse without host round trips; anything it cannot finish (pass limit, a tree deeper than the stack) goes the old way
+      bool ok = false;
+      uint32_t emitted = 0, levels = 0;
+      LB_CHECK(build_dev(s, n, leaf_boxes, vals_b, stack_capacity, children, node_boxes, queue[0], queue[1], ref_base, leaf_tag, remap ? 1u : 0u,
+                          nodes_out, arena, &ok, &emitted, &levels));
+      if (ok) {
+        info->root_ref = ref_base + 0u;
+        if (order_out) LB_CHECK(hipMemcpyAsync(order_out, vals_b, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
+        LB_CHECK(hipGetLastError());
+        LB_CHECK(hipStreamSynchronize(s));
+        info->node_span = emitted;
+        info->depth4 = levels;
+        break;
+      }
+      use_ploc = false;
+      continue;
+    }
     if (use_ploc) {
       bool ok = false;
       LB_CHECK(ploc_build(s, n, leaf_boxes, vals_b, children, node_boxes, &root, &ok, arena, scan_bytes));
