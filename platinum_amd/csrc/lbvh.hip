@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <cmath>
+
 
 #include "kernels.h"
 #include "pt_shade.h"
@@ -328,6 +330,27 @@ struct BuildState {
   PlocSlot ploc[2];                  // pass p reads slot p & 1 and writes slot (p + 1) & 1
   uint32_t level_count[kMaxLevels];  // collapse: nodes queued for level l + 1 by level l (zeroed before the first level)
 };
+
+// The first kHeadLevels collapse levels (level l holds at most 4^l nodes: <= 1 024 up to level 5) in one single-block launch, block barriers
+// between the levels: a level is a chain of ~6 dependent loads whatever its size, so a launch per tiny level cost ~27 us each.
+constexpr uint32_t kHeadLevels = 6;
+__global__ void __launch_bounds__(1024) k_emit_sah_head(const BuildState* st, uint32_t ploc_slot, uint32_t levels, uint2* q0, uint2* q1, uint32_t* level_count,
+                                                         uint32_t ref_base, uint32_t leaf_tag, uint32_t remap, const uint2* __restrict__ children,
+                                                         const Box* __restrict__ leaf_boxes, const uint32_t* __restrict__ order,
+                                                         const Box* __restrict__ node_boxes, BvhNode* __restrict__ nodes) {
+  if (st->ploc[ploc_slot].ok == 0) return;
+  uint32_t n_in = 1, before = 0;
+  for (uint32_t level = 0; level < levels; level++) {
+    if (threadIdx.x < n_in)
+      emit_sah_node(threadIdx.x, (level & 1u) ? q1 : q0, (level & 1u) ? q0 : q1, &level_count[level], before + n_in, ref_base, leaf_tag, remap, children,
+                    leaf_boxes, order, node_boxes, nodes);
+    __threadfence_block();
+    __syncthreads();
+    before += n_in;
+    n_in = __hip_atomic_load(&level_count[level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (n_in > 1024u) n_in = 0;  // (cannot happen: 4^level <= 1 024)
+  }
+}
 
 // One collapse level, its size and numbering base read from the counts the levels before it left (level 0: the root alone).
 __global__ void __launch_bounds__(256) k_emit_sah_dev(const BuildState* st, uint32_t ploc_slot, uint32_t level, const uint2* __restrict__ q_in,
@@ -732,8 +755,8 @@ done:
 
 
 // The device-driven build: PLOC passes, PLOC tail and collapse levels launched back to back (kernels above); the host reads the state
-// every kSyncPasses passes / kSyncLevels levels.  PTAMD_BVH_LEGACY=1 selects the per-pass / per-level launches (the fallback, kept for A/B).
-constexpr uint32_t kSyncPasses = 4, kSyncLevels = 6, kPlocBlocks = 1024;
+// after each batch of passes / levels (2 + 1-2 read-backs on C3 where there were 46).  PTAMD_BVH_LEGACY=1 selects the per-pass / per-level launches (the fallback, kept for A/B).
+constexpr uint32_t kPlocBlocks = 1024;
 static bool device_driven_build() { static const bool on = getenv("PTAMD_BVH_LEGACY") == nullptr; return on; }
 static size_t dev_scratch_bytes(uint32_t n) {
   return 2 * (Arena::pad(sizeof(uint32_t) * (size_t)n) + Arena::pad(sizeof(Box) * (size_t)n)) + Arena::pad(sizeof(uint32_t) * (size_t)n) +
@@ -759,12 +782,15 @@ static hipError_t build_dev(hipStream_t s, uint32_t n, const Box* leaf_boxes, co
   LB_CHECK(hipMemsetAsync(st, 0, sizeof(BuildState), s));
   hipLaunchKernelGGL(k_ploc_state_init, dim3(1), dim3(1), 0, s, st, n);
   hipLaunchKernelGGL(k_ploc_init, dim3((n + 255) / 256), dim3(256), 0, s, n, leaf_boxes, order, ref0, box0);
-  // ---- PLOC passes down to kPlocTail clusters ----
+  // ---- PLOC passes down to kPlocTail clusters: as many as the count the host last saw should need (a pass keeps <~ 80 % of the clusters);
+  //      passes that turn out to be one too many do nothing ----
   while (bound > kPlocTail) {
-    if (pass > 256) goto done;  // >= 1 merge per pass is guaranteed, ~30 % per pass is typical: a degenerate input (-> radix tree)
+    if (pass > 256) goto done;  // >= 1 merge per pass is guaranteed, ~25 % per pass is typical: a degenerate input (-> radix tree)
     const uint32_t blocks = (bound + 255) / 256;
     const uint32_t tiles = blocks < kPlocBlocks ? blocks : kPlocBlocks;
-    for (uint32_t k = 0; k < kSyncPasses; k++, pass++) {
+    uint32_t batch = (uint32_t)std::ceil(std::log((double)bound / (double)kPlocTail) / 0.2231);
+    batch = batch < 2 ? 2 : batch > 48 ? 48 : batch;
+    for (uint32_t k = 0; k < batch; k++, pass++) {
       hipLaunchKernelGGL(k_ploc_nn_dev, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, s, st, pass, box0, box1, nn);
       hipLaunchKernelGGL(k_ploc_count_dev, dim3(tiles), dim3(256), 0, s, st, pass, nn, block_counts);
       hipLaunchKernelGGL(k_ploc_apply_dev, dim3(tiles), dim3(256), 0, s, st, pass, n, nn, block_counts, ref0, ref1, box0, box1, children, node_boxes);
@@ -775,24 +801,35 @@ static hipError_t build_dev(hipStream_t s, uint32_t n, const Box* leaf_boxes, co
     bound = h.ploc[0].cur;
   }
   hipLaunchKernelGGL(k_ploc_tail_dev, dim3(1), dim3(1024), 0, s, st, pass & 1u, n, ref0, ref1, box0, box1, children, node_boxes, counts);
-  // ---- level-synchronous SAH collapse; the root is the last binary node created ----
+  // ---- level-synchronous SAH collapse; the root is the last binary node created.  First batch: the levels a balanced tree has and
+  //      eight more; further batches of six while the last level still queued something ----
   hipLaunchKernelGGL(k_seed_queue, dim3(1), dim3(1), 0, s, q0, counts, n - 2);
-  while (!finished) {
-    for (uint32_t k = 0; k < kSyncLevels; k++, level++) {
-      if ((level + 1) * 3 > stack_capacity || level + 1 >= kMaxLevels) break;  // (whether the tree really is this deep shows below)
-      hipLaunchKernelGGL(k_emit_sah_dev, dim3((level_bound + 255) / 256), dim3(256), 0, s, st, pass & 1u, level, (level & 1u) ? q1 : q0, (level & 1u) ? q0 : q1,
-                         st->level_count, ref_base, leaf_tag, remap, children, leaf_boxes, order, node_boxes, nodes_out);
-      level_bound = level_bound > n / 4 ? n : level_bound * 4;
-    }
-    LB_CHECK(hipMemcpyAsync(&h, st, sizeof(BuildState), hipMemcpyDeviceToHost, s));
-    LB_CHECK(hipStreamSynchronize(s));
-    if (!h.ploc[pass & 1u].ok) goto done;
-    // levels done so far: level l exists when l == 0 or level l - 1 queued something for it
-    total = 0; done_levels = 0;
-    for (uint32_t l = 0, n_in = 1; l < level && n_in > 0; l++) { total += n_in; done_levels = l + 1; n_in = h.level_count[l]; finished = n_in == 0; }
-    if (!finished) {
-      if ((level + 1) * 3 > stack_capacity || level + 1 >= kMaxLevels) goto done;  // deeper than the traversal stack: the caller falls back
-      level_bound = std::min<uint64_t>((uint64_t)h.level_count[level - 1], (uint64_t)n);  // the next level's real size
+  {
+    const uint32_t allowed = std::min<uint32_t>(stack_capacity / 3, kMaxLevels - 1);  // levels the traversal stack can hold
+    const uint32_t head = std::min(kHeadLevels, allowed);
+    if (head) hipLaunchKernelGGL(k_emit_sah_head, dim3(1), dim3(1024), 0, s, st, pass & 1u, head, q0, q1, st->level_count, ref_base, leaf_tag, remap, children,
+                                 leaf_boxes, order, node_boxes, nodes_out);
+    level = head;
+    for (uint32_t l = 0; l < head; l++) level_bound = level_bound > n / 4 ? n : level_bound * 4;
+    uint32_t batch = (uint32_t)std::ceil(std::log((double)n) / std::log(4.0)) + 8;
+    batch = batch > head ? batch - head : 1;
+    while (!finished) {
+      for (uint32_t k = 0; k < batch && level < allowed; k++, level++) {
+        hipLaunchKernelGGL(k_emit_sah_dev, dim3((level_bound + 255) / 256), dim3(256), 0, s, st, pass & 1u, level, (level & 1u) ? q1 : q0, (level & 1u) ? q0 : q1,
+                           st->level_count, ref_base, leaf_tag, remap, children, leaf_boxes, order, node_boxes, nodes_out);
+        level_bound = level_bound > n / 4 ? n : level_bound * 4;
+      }
+      batch = 6;
+      LB_CHECK(hipMemcpyAsync(&h, st, sizeof(BuildState), hipMemcpyDeviceToHost, s));
+      LB_CHECK(hipStreamSynchronize(s));
+      if (!h.ploc[pass & 1u].ok) goto done;
+      // levels done so far: level l exists when l == 0 or level l - 1 queued something for it
+      total = 0; done_levels = 0;
+      for (uint32_t l = 0, n_in = 1; l < level && n_in > 0; l++) { total += n_in; done_levels = l + 1; n_in = h.level_count[l]; finished = n_in == 0; }
+      if (!finished) {
+        if (level >= allowed) goto done;  // deeper than the traversal stack: the caller falls back
+        level_bound = std::min<uint64_t>((uint64_t)h.level_count[level - 1], (uint64_t)n);  // the next level's real size
+      }
     }
   }
   if (total >= 1 && total <= n - 1) {
@@ -813,8 +850,25 @@ struct TreeInfo { uint32_t root_ref = kInvalidRef, node_span = 0, depth4 = 0; };
 // Internal child refs are `ref_base + index`, leaf refs `leaf_tag | id` with id = the leaf's index in leaf_boxes[] when
 // `remap`, its position in the Morton order otherwise (the caller then reorders its leaf array by order_out[], n entries,
 // sorted position -> index).  nodes_out needs room for n - 1 records.
+static hipError_t tree_arena_bytes(uint32_t n, size_t* sort_bytes_out, size_t* scan_bytes_out, size_t* bytes) {
+  size_t sort_bytes = 0, scan_bytes = 0;
+  *bytes = 0;
+  if (n >= 2) {
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 63, 0);
+    if (e != hipSuccess) return e;
+    const size_t N = n;
+    *bytes = Arena::pad(sizeof(int) * 8) + Arena::pad(4 * sizeof(uint32_t)) + 2 * Arena::pad(sizeof(uint64_t) * N) + 2 * Arena::pad(sizeof(uint32_t) * N) +
+             Arena::pad(sizeof(uint2) * (N - 1)) + Arena::pad(sizeof(uint32_t) * (N - 1)) + Arena::pad(sizeof(uint32_t) * N) + Arena::pad(sizeof(uint32_t) * (N - 1)) +
+             Arena::pad(sizeof(Box) * (N - 1)) + 2 * Arena::pad(sizeof(uint2) * N) + Arena::pad(sort_bytes) +
+             std::max(ploc_scratch_bytes(n, &scan_bytes), dev_scratch_bytes(n));
+  }
+  if (sort_bytes_out) *sort_bytes_out = sort_bytes;
+  if (scan_bytes_out) *scan_bytes_out = scan_bytes;
+  return hipSuccess;
+}
+// (`scratch`: tree_arena_bytes(n) bytes of device memory, the caller's)
 static hipError_t build_tree(hipStream_t s, uint32_t n, const Box* leaf_boxes, uint32_t stack_capacity, bool use_ploc, BvhNode* nodes_out,
-                             uint32_t ref_base, uint32_t leaf_tag, bool remap, uint32_t* order_out, TreeInfo* info) {
+                             uint32_t ref_base, uint32_t leaf_tag, bool remap, uint32_t* order_out, char* scratch, size_t scratch_bytes, TreeInfo* info) {
   hipError_t err = hipSuccess;
   *info = TreeInfo{};
   const uint32_t blocks = (n + 255) / 256;
@@ -833,15 +887,9 @@ static hipError_t build_tree(hipStream_t s, uint32_t n, const Box* leaf_boxes, u
     info->root_ref = leaf_tag | 0u;
     return hipSuccess;
   }
-  LB_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 63, s));
-  {
-    const size_t N = n;
-    arena.cap = Arena::pad(sizeof(int) * 8) + Arena::pad(4 * sizeof(uint32_t)) + 2 * Arena::pad(sizeof(uint64_t) * N) + 2 * Arena::pad(sizeof(uint32_t) * N) +
-                Arena::pad(sizeof(uint2) * (N - 1)) + Arena::pad(sizeof(uint32_t) * (N - 1)) + Arena::pad(sizeof(uint32_t) * N) + Arena::pad(sizeof(uint32_t) * (N - 1)) +
-                Arena::pad(sizeof(Box) * (N - 1)) + 2 * Arena::pad(sizeof(uint2) * N) + Arena::pad(sort_bytes) +
-                std::max(ploc_scratch_bytes(n, &scan_bytes), dev_scratch_bytes(n));
-    LB_CHECK(hipMalloc((void**)&arena.base, arena.cap));
-  }
+  LB_CHECK(tree_arena_bytes(n, &sort_bytes, &scan_bytes, &arena.cap));
+  if (arena.cap > scratch_bytes) return hipErrorOutOfMemory;  // (the callers size the scratch with tree_arena_bytes)
+  arena.base = scratch;
   bounds = arena.take<int>(8);
   counters = arena.take<uint32_t>(4);  // [0] max binary depth, [1] emitted (fallback), [2] next level size, [3] unused
   LB_CHECK(hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), s));
@@ -934,15 +982,28 @@ static hipError_t build_tree(hipStream_t s, uint32_t n, const Box* leaf_boxes, u
   }
 
 done:
-  if (arena.base) (void)hipFree(arena.base);
   return err;
 }
 
 }  // namespace
 
+hipError_t LbvhScratch::ensure(size_t bytes) {
+  if (bytes <= cap) return hipSuccess;
+  release();
+  hipError_t e = hipMalloc((void**)&base, bytes);
+  if (e != hipSuccess) { base = nullptr; return e; }
+  cap = bytes;
+  return hipSuccess;
+}
+void LbvhScratch::release() {
+  if (base) (void)hipFree(base);
+  base = nullptr;
+  cap = 0;
+}
+
 // Flattens the instanced scene to world-space triangles and builds ONE BVH over them (the default: fewest node visits per ray).
 hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_count, uint32_t tri_count, uint32_t stack_capacity,
-                      LbvhResult* out) {
+                      LbvhScratch* scratch, LbvhResult* out) {
   *out = LbvhResult{};
   if (tri_count == 0) return hipSuccess;
   hipError_t err = hipSuccess;
@@ -952,17 +1013,22 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
   TreeInfo info;
   const bool use_ploc = getenv("PTAMD_RADIX_TREE") == nullptr;  // PLOC by default; the Karras radix tree is the fallback
 
-  Arena tmp;  // the flattening's temporaries in one allocation
+  Arena tmp;  // the flattening's temporaries and, behind them, the tree builder's: one kept allocation (LbvhScratch)
+  size_t tree_bytes = 0;
+  char* tree_scratch = nullptr;
+  LB_CHECK(tree_arena_bytes(n, nullptr, nullptr, &tree_bytes));
   tmp.cap = Arena::pad(sizeof(TriRec) * (size_t)n) + Arena::pad(sizeof(Box) * (size_t)n) + Arena::pad(sizeof(uint32_t) * (size_t)n) +
-            Arena::pad(sizeof(BvhNode) * (size_t)(n > 1 ? n - 1 : 1));
-  LB_CHECK(hipMalloc((void**)&tmp.base, tmp.cap));
+            Arena::pad(sizeof(BvhNode) * (size_t)(n > 1 ? n - 1 : 1)) + Arena::pad(tree_bytes);
+  LB_CHECK(scratch->ensure(tmp.cap));
+  tmp.base = scratch->base;
   tris_tmp = tmp.take<TriRec>(n);
   leaf_boxes = tmp.take<Box>(n);
   order = tmp.take<uint32_t>(n);
   nodes_tmp = tmp.take<BvhNode>(n > 1 ? n - 1 : 1);
+  tree_scratch = tmp.take<char>(tree_bytes);
   LB_CHECK(hipMalloc(&out->tris, sizeof(TriRec) * (size_t)n));
   hipLaunchKernelGGL(k_flatten, dim3(blocks), dim3(256), 0, s, S, instance_count, n, tris_tmp, leaf_boxes);
-  LB_CHECK(build_tree(s, n, leaf_boxes, stack_capacity, use_ploc, nodes_tmp, 0u, kLeafBit, false, order, &info));
+  LB_CHECK(build_tree(s, n, leaf_boxes, stack_capacity, use_ploc, nodes_tmp, 0u, kLeafBit, false, order, tree_scratch, tree_bytes, &info));
   hipLaunchKernelGGL(k_reorder_tris, dim3(blocks), dim3(256), 0, s, (int)n, order, tris_tmp, out->tris);  // triangles in leaf (Morton) order
   if (info.node_span) {  // keep exactly the records the tree uses
     LB_CHECK(hipMalloc(&out->nodes, sizeof(BvhNode) * (size_t)info.node_span));
@@ -975,7 +1041,6 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
   out->depth4 = info.depth4;
 
 done:
-  if (tmp.base) (void)hipFree(tmp.base);
   if (err != hipSuccess) {
     (void)hipFree(out->nodes); (void)hipFree(out->tris);
     *out = LbvhResult{};
@@ -1044,12 +1109,15 @@ __global__ void k_box_bounds(const Box* __restrict__ b, MeshTrav* __restrict__ o
 }  // namespace
 
 hipError_t build_two_level(hipStream_t s, const DeviceScene& S, const MeshInfo* meshes, uint32_t mesh_count, uint32_t instance_count,
-                           uint32_t tri_count, uint32_t stack_capacity, LbvhResult* out) {
+                           uint32_t tri_count, uint32_t stack_capacity, LbvhScratch* scratch, LbvhResult* out) {
   *out = LbvhResult{};
   if (tri_count == 0 || instance_count == 0) return hipSuccess;
   hipError_t err = hipSuccess;
   Box *tri_boxes = nullptr, *inst_boxes = nullptr, *mesh_boxes = nullptr;
   BvhNode* nodes_tmp = nullptr;
+  Arena tmp;
+  size_t tree_bytes = 0, tb = 0;
+  char* tree_scratch = nullptr;
   TreeInfo tlas;
   uint32_t base = 0, deepest_blas = 0, max_mesh_tris = 0;
   size_t capacity = instance_count;
@@ -1057,24 +1125,33 @@ hipError_t build_two_level(hipStream_t s, const DeviceScene& S, const MeshInfo* 
   std::vector<MeshTrav> mt(mesh_count);
   for (uint32_t m = 0; m < mesh_count; m++) { capacity += meshes[m].tri_count; max_mesh_tris = std::max(max_mesh_tris, meshes[m].tri_count); }
 
+  // temporaries: one kept allocation (LbvhScratch); the tree builder's part is sized for the largest tree (TLAS or a BLAS)
+  LB_CHECK(tree_arena_bytes(instance_count, nullptr, nullptr, &tree_bytes));
+  LB_CHECK(tree_arena_bytes(max_mesh_tris, nullptr, nullptr, &tb));
+  tree_bytes = std::max(tree_bytes, tb);
+  tmp.cap = Arena::pad(sizeof(Box) * (size_t)tri_count) + Arena::pad(sizeof(Box) * (size_t)instance_count) +
+            Arena::pad(sizeof(Box) * (size_t)std::max(1u, max_mesh_tris)) + Arena::pad(sizeof(BvhNode) * capacity) + Arena::pad(tree_bytes);
+  LB_CHECK(scratch->ensure(tmp.cap));
+  tmp.base = scratch->base;
+  tri_boxes = tmp.take<Box>(tri_count);
+  inst_boxes = tmp.take<Box>(instance_count);
+  mesh_boxes = tmp.take<Box>(std::max(1u, max_mesh_tris));
+  nodes_tmp = tmp.take<BvhNode>(capacity);
+  tree_scratch = tmp.take<char>(tree_bytes);
   LB_CHECK(hipMalloc(&out->tris, sizeof(TriRec) * (size_t)tri_count));
-  LB_CHECK(hipMalloc(&tri_boxes, sizeof(Box) * (size_t)tri_count));
-  LB_CHECK(hipMalloc(&inst_boxes, sizeof(Box) * (size_t)instance_count));
-  LB_CHECK(hipMalloc(&mesh_boxes, sizeof(Box) * (size_t)std::max(1u, max_mesh_tris)));
-  LB_CHECK(hipMalloc(&nodes_tmp, sizeof(BvhNode) * capacity));
   LB_CHECK(hipMalloc(&out->mesh_trav, sizeof(MeshTrav) * (size_t)mesh_count));
   LB_CHECK(hipMemsetAsync(out->mesh_trav, 0, sizeof(MeshTrav) * (size_t)mesh_count, s));
   // world-space triangles in flattening order (the intersection contract's triangles) and the instances' world boxes
   hipLaunchKernelGGL(k_flatten, dim3((tri_count + 255) / 256), dim3(256), 0, s, S, instance_count, tri_count, out->tris, tri_boxes);
   hipLaunchKernelGGL(k_instance_boxes, dim3(instance_count), dim3(256), 0, s, S, tri_boxes, inst_boxes);
-  LB_CHECK(build_tree(s, instance_count, inst_boxes, stack_capacity, use_ploc, nodes_tmp, 0u, kInstBit, true, nullptr, &tlas));
+  LB_CHECK(build_tree(s, instance_count, inst_boxes, stack_capacity, use_ploc, nodes_tmp, 0u, kInstBit, true, nullptr, tree_scratch, tree_bytes, &tlas));
   base = tlas.node_span;
   for (uint32_t m = 0; m < mesh_count; m++) {
     const MeshInfo mesh = meshes[m];
     if (mesh.tri_count == 0) { mt[m].root_ref = kInvalidRef; continue; }
     TreeInfo blas;
     hipLaunchKernelGGL(k_mesh_boxes, dim3((mesh.tri_count + 255) / 256), dim3(256), 0, s, S, mesh, mesh_boxes);
-    LB_CHECK(build_tree(s, mesh.tri_count, mesh_boxes, stack_capacity, use_ploc, nodes_tmp + base, base, kLeafBit, true, nullptr, &blas));
+    LB_CHECK(build_tree(s, mesh.tri_count, mesh_boxes, stack_capacity, use_ploc, nodes_tmp + base, base, kLeafBit, true, nullptr, tree_scratch, tree_bytes, &blas));
     LB_CHECK(hipMemcpyAsync(&out->mesh_trav[m].root_ref, &blas.root_ref, sizeof(uint32_t), hipMemcpyHostToDevice, s));
     if (blas.node_span) hipLaunchKernelGGL(k_root_bounds, dim3(1), dim3(1), 0, s, nodes_tmp + base, out->mesh_trav + m);
     else hipLaunchKernelGGL(k_box_bounds, dim3(1), dim3(1), 0, s, mesh_boxes, out->mesh_trav + m);
@@ -1093,7 +1170,6 @@ hipError_t build_two_level(hipStream_t s, const DeviceScene& S, const MeshInfo* 
   out->depth4 = tlas.depth4 + deepest_blas;
 
 done:
-  (void)hipFree(tri_boxes); (void)hipFree(inst_boxes); (void)hipFree(mesh_boxes); (void)hipFree(nodes_tmp);
   if (err != hipSuccess) {
     (void)hipFree(out->nodes); (void)hipFree(out->tris); (void)hipFree(out->mesh_trav);
     *out = LbvhResult{};

@@ -369,9 +369,9 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
     if (r->two_level) {
       PT_HIP(r->inst_trav.upload(itrav));
       be = build_two_level(r->stream, S, hs.meshes.data(), (uint32_t)hs.meshes.size(), r->instance_count, r->tri_count,
-                           (uint32_t)(kLdsStack + kSpillStack), &r->bvh);
+                           (uint32_t)(kLdsStack + kSpillStack), &r->bvh_scratch, &r->bvh);
     } else {
-      be = build_lbvh(r->stream, S, r->instance_count, r->tri_count, (uint32_t)(kLdsStack + kSpillStack), &r->bvh);
+      be = build_lbvh(r->stream, S, r->instance_count, r->tri_count, (uint32_t)(kLdsStack + kSpillStack), &r->bvh_scratch, &r->bvh);
     }
     if (be != hipSuccess)
       return fail(be == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP, std::string("LBVH build failed: ") + hipGetErrorString(be));

@@ -101,6 +101,7 @@ struct pt_renderer {
   DevBuf<pt_alias_entry> env_alias_d;
   std::vector<pt_alias_entry> env_alias;
   LbvhResult bvh{};
+  LbvhScratch bvh_scratch{};  // the builder's temporaries, kept between builds (release_all gives them back)
   DeviceScene S{};
   pt_render_params params{};
   pt_constants constants{};
@@ -174,6 +175,7 @@ struct pt_renderer {
     positions.release(); vdata.release(); indices.release(); slots.release(); meshes.release(); instances.release();
     materials.release(); lights_d.release(); tex_pixels.release(); textures.release(); env_alias_d.release(); scene_d.release(); shade_recs.release(); light_recs.release(); light_cdf.release();
     inst_trav.release();
+    bvh_scratch.release();
     for (int k = 0; k < 2; k++) { st_rayO[k].release(); st_rayD[k].release(); st_att[k].release(); }
     seg_active[0].release(); seg_active[1].release(); seg_shadow.release(); seg_poison.release(); wave_stats.release(); chunk_table[0].release(); chunk_table[1].release(); gmon_buckets_d.release(); render_target.release();
     hit.release(); sq_o.release(); sq_d.release(); sq_c.release(); Lbuf.release(); acc_own.release(); spill.release();
