@@ -69,7 +69,8 @@ struct LbvhResult {
   uint32_t root_ref = kInvalidRef;
   uint32_t node_count = 0;    // 4-wide nodes emitted
   uint32_t max_depth = 0;     // of the binary tree
-  uint32_t depth4 = 0;        // levels of the 4-wide tree (the traversal stack needs <= 3 entries per level)
+  uint32_t depth4 = 0;        // levels of the tree (the traversal stack needs <= 3 entries per level; 5 when wide6)
+  bool wide6 = false;         // nodes[] holds BvhNode6 records (pt_device.h)
 };
 // The builder's temporaries: ONE device allocation that is kept between builds and only ever grows (a hipFree is a device synchronisation
 // and took ~0.2 ms of a 2.2 ms build; C3 needs ~0.4 GB).  Owned by the renderer; release() gives the memory back.

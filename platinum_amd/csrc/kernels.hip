@@ -283,9 +283,11 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DeviceScene S, PathState st, 
 #endif
 constexpr uint32_t kTraceBlock2 = PT_TWO_BLOCK;  // two-level kernels: ONE block per CU (4 waves per SIMD) sharing the staged node array
 constexpr uint32_t kLdsNodes = PT_TWO_LDS_NODES; // 64 KB of nodes in LDS beside the 88 KB of stacks and leaf queues of 1024 lanes (152 of 160 KB)
-template <bool ANY, bool COUNT, bool TWO>
+template <bool ANY, bool COUNT, bool TWO, bool W6 = false>
 __device__ __forceinline__ void wave_traverse(const DeviceScene& S, const BvhNode* lds_nodes, TravState& ts, TraversalCount* tc) {
-  if (ts.cur != kInvalidRef && ts.st.npend <= kPendLeaves - 4) {
+  // room a node step needs in the lane's leaf queue: one entry per child it can queue (4-wide), one entry per node (6-wide: a range)
+  constexpr int kRoom = W6 ? 1 : 4, kRows = W6 ? kPendLeaves6 : kPendLeaves;
+  if (ts.cur != kInvalidRef && ts.st.npend <= kRows - kRoom) {
     if (TWO) {
       // Exit markers are handled at once; ENTERING an instance (two dependent loads, three divides) is voted on like the
       // triangle tests: it runs when half of the lanes that can advance are waiting at an instance, or nobody has a node.
@@ -298,19 +300,22 @@ __device__ __forceinline__ void wave_traverse(const DeviceScene& S, const BvhNod
       } else if (at_node) {
         if (lds_nodes) trav_node<COUNT, true>(lds_nodes, ts, tc); else trav_node<COUNT, true>(S.nodes, ts, tc);
       }
+    } else if (W6) {
+      trav_node6<COUNT>(S.nodes, ts, tc);
     } else {
       trav_node<COUNT, false>(S.nodes, ts, tc);
     }
   }
   const bool pending = ts.st.npend > 0;
-  const bool stuck = pending && (ts.cur == kInvalidRef || ts.st.npend > kPendLeaves - 4);
+  const bool stuck = pending && (ts.cur == kInvalidRef || ts.st.npend > kRows - kRoom);
   const bool advancing = ts.cur != kInvalidRef && !stuck;
   const unsigned long long mp = __ballot(pending);
   if (mp == 0) return;
   // triangle round when half of the lanes holding a ray have a queued leaf, a lane's queue is full, or nobody can advance
-  const bool go = 2 * __popcll(mp) >= __popcll(__ballot(1)) || __ballot(ts.st.npend > kPendLeaves - 4) != 0 || __ballot(advancing) == 0;
+  const bool go = 2 * __popcll(mp) >= __popcll(__ballot(1)) || __ballot(ts.st.npend > kRows - kRoom) != 0 || __ballot(advancing) == 0;
   if (go && pending) {
-    if (trav_pending_leaf<ANY, COUNT>(S, ts, tc)) { ts.cur = kInvalidRef; ts.st.npend = 0; ts.st.sp = 0; }
+    const bool fin = W6 ? trav_pending_leaf6<ANY, COUNT>(S, ts, tc) : trav_pending_leaf<ANY, COUNT>(S, ts, tc);
+    if (fin) { ts.cur = kInvalidRef; ts.st.npend = 0; ts.st.sp = 0; }
   }
 }
 
@@ -325,13 +330,13 @@ __device__ __forceinline__ const BvhNode* stage_nodes(const DeviceScene& S, BvhN
 }
 
 // ---- closest hit ---------------------------------------------------------------------------------------------------
-template <bool COUNT, bool TWO>
+template <bool COUNT, bool TWO, bool W6 = false>
 __global__ void __launch_bounds__(TWO ? kTraceBlock2 : kBlock, TWO ? PT_TWO_BLOCKS_PER_CU : PT_TRACE_WAVES)
 k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments seg, uint32_t cur, BatchCounters* __restrict__ ctr, uint32_t bounce,
                 uint32_t* __restrict__ spill, int32_t* __restrict__ hitlog, uint32_t log_stride) {
   constexpr uint32_t kTB = TWO ? kTraceBlock2 : kBlock;
-  __shared__ uint32_t lds_stack[kLdsStack + 1][kTB];
-  __shared__ uint32_t lds_pend[kPendLeaves + 1][kTB];
+  __shared__ uint32_t lds_stack[(W6 ? kLdsStack6 : kLdsStack) + 1][kTB];
+  __shared__ uint32_t lds_pend[(W6 ? kPendLeaves6 : kPendLeaves) + 1][kTB];
   __shared__ BvhNode lds_nodes_buf[TWO && kLdsNodes ? kLdsNodes : 1];
   const BvhNode* lds_nodes = TWO && kLdsNodes ? stage_nodes(S, lds_nodes_buf) : nullptr;
   const uint32_t lane = wave_lane();
@@ -377,7 +382,7 @@ k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments se
       continue;
     }
     while (ray != kInvalidRef) {
-      wave_traverse<false, COUNT, TWO>(S, lds_nodes, ts, &tc);
+      wave_traverse<false, COUNT, TWO, W6>(S, lds_nodes, ts, &tc);
       if (ts.cur == kInvalidRef && ts.st.npend == 0) finish();
       // lanes still in this loop vote: leave for a refill once the wave has emptied below the threshold
       if (refill && !src.exhausted && (uint32_t)__popcll(__ballot(ray != kInvalidRef)) < refill) break;
@@ -634,13 +639,13 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
 }
 
 // ---- shadow (any hit) --------------------------------------------------------------------------------------------------
-template <bool COUNT, bool TWO>
+template <bool COUNT, bool TWO, bool W6 = false>
 __global__ void __launch_bounds__(TWO ? kTraceBlock2 : kBlock, TWO ? PT_TWO_BLOCKS_PER_CU : PT_TRACE_WAVES)
 k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments seg, BatchCounters* __restrict__ ctr, uint32_t bounce,
                uint32_t* __restrict__ spill) {
   constexpr uint32_t kTB = TWO ? kTraceBlock2 : kBlock;
-  __shared__ uint32_t lds_stack[kLdsStack + 1][kTB];
-  __shared__ uint32_t lds_pend[kPendLeaves + 1][kTB];
+  __shared__ uint32_t lds_stack[(W6 ? kLdsStack6 : kLdsStack) + 1][kTB];
+  __shared__ uint32_t lds_pend[(W6 ? kPendLeaves6 : kPendLeaves) + 1][kTB];
   __shared__ BvhNode lds_nodes_buf[TWO && kLdsNodes ? kLdsNodes : 1];
   const BvhNode* lds_nodes = TWO && kLdsNodes ? stage_nodes(S, lds_nodes_buf) : nullptr;
   const uint32_t lane = wave_lane();
@@ -683,7 +688,7 @@ k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments 
       continue;
     }
     while (ray != kInvalidRef) {
-      wave_traverse<true, COUNT, TWO>(S, lds_nodes, ts, &tc);
+      wave_traverse<true, COUNT, TWO, W6>(S, lds_nodes, ts, &tc);
       if (ts.cur == kInvalidRef && ts.st.npend == 0) finish();
       if (refill && !src.exhausted && (uint32_t)__popcll(__ballot(ray != kInvalidRef)) < refill) break;
     }
@@ -896,6 +901,13 @@ void launch_trace_closest(hipStream_t s, uint32_t grid, const DeviceScene& S, Pa
       hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(kTraceBlock2), 0, s, S, st, hit, seg, cur, ctr, bounce, spill, hitlog, log_stride);
     return;
   }
+  if (S.wide6) {
+    if (count)
+      hipLaunchKernelGGL((k_trace_closest<true, false, true>), dim3(grid), dim3(kBlock), 0, s, S, st, hit, seg, cur, ctr, bounce, spill, hitlog, log_stride);
+    else
+      hipLaunchKernelGGL((k_trace_closest<false, false, true>), dim3(grid), dim3(kBlock), 0, s, S, st, hit, seg, cur, ctr, bounce, spill, hitlog, log_stride);
+    return;
+  }
   if (count)
     hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(grid), dim3(kBlock), 0, s, S, st, hit, seg, cur, ctr, bounce, spill, hitlog, log_stride);
   else
@@ -912,6 +924,11 @@ void launch_trace_shadow(hipStream_t s, uint32_t grid, const DeviceScene& S, Sha
   if (S.two_level) {
     if (count) hipLaunchKernelGGL((k_trace_shadow<true, true>), dim3(grid), dim3(kTraceBlock2), 0, s, S, sq, Lbuf, seg, ctr, bounce, spill);
     else hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(grid), dim3(kTraceBlock2), 0, s, S, sq, Lbuf, seg, ctr, bounce, spill);
+    return;
+  }
+  if (S.wide6) {
+    if (count) hipLaunchKernelGGL((k_trace_shadow<true, false, true>), dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, seg, ctr, bounce, spill);
+    else hipLaunchKernelGGL((k_trace_shadow<false, false, true>), dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, seg, ctr, bounce, spill);
     return;
   }
   if (count) hipLaunchKernelGGL((k_trace_shadow<true, false>), dim3(grid), dim3(kBlock), 0, s, S, sq, Lbuf, seg, ctr, bounce, spill);

@@ -308,6 +308,58 @@ __device__ __forceinline__ void emit_sah_node(uint32_t t, const uint2* __restric
   }
   nodes[dense] = quantize_node4(boxes, refs, count);
 }
+// The 6-wide form (BvhNode6; one-BVH structure, device-driven build): open the internal child with the largest surface area until six
+// slots are used; internal children first, then the leaves.  One reservation of consecutive node records AND one of consecutive triangle
+// slots per node: the leaf children of a node become base_leaf + 0, 1, ... (tri_perm[slot] = the triangle's position in the Morton
+// order; k_reorder_tris6 places the triangles accordingly).
+__device__ __forceinline__ void emit_sah_node6(uint32_t t, const uint2* __restrict__ q_in, uint2* __restrict__ q_out, uint32_t* n_out, uint32_t* leaf_out,
+                                               uint32_t next_base, const uint2* __restrict__ children, const Box* __restrict__ leaf_boxes,
+                                               const uint32_t* __restrict__ order, const Box* __restrict__ node_boxes, uint32_t* __restrict__ tri_perm,
+                                               BvhNode* __restrict__ nodes) {
+  const uint32_t i = q_in[t].x, dense = q_in[t].y;
+  auto box_of = [&](uint32_t ref) { return (ref & kLeafBit) ? leaf_boxes[order[ref & ~kLeafBit]] : node_boxes[ref]; };
+  auto half_area = [](const Box& b) {
+    const float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
+    return x * y + y * z + z * x;
+  };
+  const uint2 ch = children[i];
+  uint32_t refs[6] = {ch.x, ch.y, kInvalidRef, kInvalidRef, kInvalidRef, kInvalidRef};
+  Box bx[6];
+  bx[0] = box_of(refs[0]); bx[1] = box_of(refs[1]);
+  int count = 2;
+  while (count < 6) {
+    int best = -1;
+    float best_area = -1.0f;
+    for (int k = 0; k < count; k++)
+      if (!(refs[k] & kLeafBit)) { const float a = half_area(bx[k]); if (a > best_area) { best_area = a; best = k; } }
+    if (best < 0) break;
+    const uint2 g = children[refs[best]];
+    refs[best] = g.x; bx[best] = box_of(g.x);
+    refs[count] = g.y; bx[count] = box_of(g.y);
+    count++;
+  }
+  uint32_t n_int = 0;
+  for (int k = 0; k < count; k++) n_int += (refs[k] & kLeafBit) ? 0u : 1u;
+  const uint32_t n_leaf = (uint32_t)count - n_int;
+  const uint32_t p_node = n_int ? atomicAdd(n_out, n_int) : 0u;
+  const uint32_t p_leaf = n_leaf ? atomicAdd(leaf_out, n_leaf) : 0u;
+  Box3 boxes[6];
+  uint32_t a_int = 0, a_leaf = 0;
+  for (int k = 0; k < count; k++) {
+    Box3 e;
+    for (int a = 0; a < 3; a++) { e.lo[a] = bx[k].lo[a]; e.hi[a] = bx[k].hi[a]; }
+    if (refs[k] & kLeafBit) {
+      boxes[n_int + a_leaf] = inflate_box(e);
+      tri_perm[p_leaf + a_leaf] = refs[k] & ~kLeafBit;
+      a_leaf++;
+    } else {
+      boxes[a_int] = inflate_box(e);
+      q_out[p_node + a_int] = make_uint2(refs[k], next_base + p_node + a_int);
+      a_int++;
+    }
+  }
+  reinterpret_cast<BvhNode6*>(nodes)[dense] = quantize_node6(boxes, (int)n_int, (int)n_leaf, next_base + p_node, p_leaf);
+}
 __global__ void __launch_bounds__(256) k_emit_sah(uint32_t n_in, const uint2* __restrict__ q_in, uint2* __restrict__ q_out,
                                                    uint32_t* __restrict__ n_out, uint32_t next_base, uint32_t ref_base, uint32_t leaf_tag,
                                                    uint32_t remap, const uint2* __restrict__ children, const Box* __restrict__ leaf_boxes,
@@ -329,40 +381,54 @@ struct PlocSlot { uint32_t cur, base, buf, ok; };  // clusters left, binary node
 struct BuildState {
   PlocSlot ploc[2];                  // pass p reads slot p & 1 and writes slot (p + 1) & 1
   uint32_t level_count[kMaxLevels];  // collapse: nodes queued for level l + 1 by level l (zeroed before the first level)
+  uint32_t leaf_count;               // 6-wide collapse: triangle slots handed out so far
 };
 
 // The first kHeadLevels collapse levels (level l holds at most 4^l nodes: <= 1 024 up to level 5) in one single-block launch, block barriers
 // between the levels: a level is a chain of ~6 dependent loads whatever its size, so a launch per tiny level cost ~27 us each.
 constexpr uint32_t kHeadLevels = 6;
-__global__ void __launch_bounds__(1024) k_emit_sah_head(const BuildState* st, uint32_t ploc_slot, uint32_t levels, uint2* q0, uint2* q1, uint32_t* level_count,
+template <bool W6>
+__global__ void __launch_bounds__(1024) k_emit_sah_head(BuildState* st, uint32_t ploc_slot, uint32_t levels, uint2* q0, uint2* q1, uint32_t* level_count,
                                                          uint32_t ref_base, uint32_t leaf_tag, uint32_t remap, const uint2* __restrict__ children,
                                                          const Box* __restrict__ leaf_boxes, const uint32_t* __restrict__ order,
-                                                         const Box* __restrict__ node_boxes, BvhNode* __restrict__ nodes) {
+                                                         const Box* __restrict__ node_boxes, uint32_t* __restrict__ tri_perm, BvhNode* __restrict__ nodes) {
   if (st->ploc[ploc_slot].ok == 0) return;
   uint32_t n_in = 1, before = 0;
   for (uint32_t level = 0; level < levels; level++) {
-    if (threadIdx.x < n_in)
-      emit_sah_node(threadIdx.x, (level & 1u) ? q1 : q0, (level & 1u) ? q0 : q1, &level_count[level], before + n_in, ref_base, leaf_tag, remap, children,
-                    leaf_boxes, order, node_boxes, nodes);
+    if (threadIdx.x < n_in) {
+      if (W6) emit_sah_node6(threadIdx.x, (level & 1u) ? q1 : q0, (level & 1u) ? q0 : q1, &level_count[level], &st->leaf_count, before + n_in, children, leaf_boxes,
+                             order, node_boxes, tri_perm, nodes);
+      else emit_sah_node(threadIdx.x, (level & 1u) ? q1 : q0, (level & 1u) ? q0 : q1, &level_count[level], before + n_in, ref_base, leaf_tag, remap, children,
+                         leaf_boxes, order, node_boxes, nodes);
+    }
     __threadfence_block();
     __syncthreads();
     before += n_in;
     n_in = __hip_atomic_load(&level_count[level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (n_in > 1024u) n_in = 0;  // (cannot happen: 4^level <= 1 024)
+    if (n_in > 1024u) n_in = 0;  // (cannot happen: the host keeps width^level <= 1 024)
   }
 }
 
 // One collapse level, its size and numbering base read from the counts the levels before it left (level 0: the root alone).
-__global__ void __launch_bounds__(256) k_emit_sah_dev(const BuildState* st, uint32_t ploc_slot, uint32_t level, const uint2* __restrict__ q_in,
+template <bool W6>
+__global__ void __launch_bounds__(256) k_emit_sah_dev(BuildState* st, uint32_t ploc_slot, uint32_t level, const uint2* __restrict__ q_in,
                                                        uint2* __restrict__ q_out, uint32_t* level_count, uint32_t ref_base, uint32_t leaf_tag,
                                                        uint32_t remap, const uint2* __restrict__ children, const Box* __restrict__ leaf_boxes,
-                                                       const uint32_t* __restrict__ order, const Box* __restrict__ node_boxes, BvhNode* __restrict__ nodes) {
+                                                       const uint32_t* __restrict__ order, const Box* __restrict__ node_boxes, uint32_t* __restrict__ tri_perm,
+                                                       BvhNode* __restrict__ nodes) {
   if (st->ploc[ploc_slot].ok == 0) return;  // PLOC gave up: the host falls back to the radix tree
   uint32_t n_in = 1, before = 0;            // nodes of this level, nodes of all levels before it
   for (uint32_t l = 0; l < level; l++) { before += n_in; n_in = st->level_count[l]; }
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= n_in) return;
-  emit_sah_node(t, q_in, q_out, &level_count[level], before + n_in, ref_base, leaf_tag, remap, children, leaf_boxes, order, node_boxes, nodes);
+  if (W6) emit_sah_node6(t, q_in, q_out, &level_count[level], &st->leaf_count, before + n_in, children, leaf_boxes, order, node_boxes, tri_perm, nodes);
+  else emit_sah_node(t, q_in, q_out, &level_count[level], before + n_in, ref_base, leaf_tag, remap, children, leaf_boxes, order, node_boxes, nodes);
+}
+// triangles in the order the 6-wide collapse numbered them: slot -> position in the Morton order -> flattening index
+__global__ void __launch_bounds__(256) k_reorder_tris6(int n, const uint32_t* __restrict__ tri_perm, const uint32_t* __restrict__ order,
+                                                        const TriRec* __restrict__ tris_in, TriRec* __restrict__ tris_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) tris_out[i] = tris_in[order[tri_perm[i]]];
 }
 __global__ void __launch_bounds__(256) k_reorder_tris(int n, const uint32_t* __restrict__ order, const TriRec* __restrict__ tris_in,
                                                        TriRec* __restrict__ tris_out) {
@@ -765,7 +831,7 @@ static size_t dev_scratch_bytes(uint32_t n) {
 // children[] / node_boxes[] / nodes_out are filled on success (*ok): *emitted 4-wide nodes in *levels levels, root = dense node 0.
 static hipError_t build_dev(hipStream_t s, uint32_t n, const Box* leaf_boxes, const uint32_t* order, uint32_t stack_capacity, uint2* children,
                             Box* node_boxes, uint2* q0, uint2* q1, uint32_t ref_base, uint32_t leaf_tag, uint32_t remap, BvhNode* nodes_out,
-                            Arena& arena, bool* ok, uint32_t* emitted, uint32_t* levels) {
+                            bool wide6, uint32_t* tri_perm, Arena& arena, bool* ok, uint32_t* emitted, uint32_t* levels) {
   hipError_t err = hipSuccess;
   *ok = false;
   const size_t mark = arena.off;
@@ -805,19 +871,27 @@ static hipError_t build_dev(hipStream_t s, uint32_t n, const Box* leaf_boxes, co
   //      eight more; further batches of six while the last level still queued something ----
   hipLaunchKernelGGL(k_seed_queue, dim3(1), dim3(1), 0, s, q0, counts, n - 2);
   {
-    const uint32_t allowed = std::min<uint32_t>(stack_capacity / 3, kMaxLevels - 1);  // levels the traversal stack can hold
-    const uint32_t head = std::min(kHeadLevels, allowed);
-    if (head) hipLaunchKernelGGL(k_emit_sah_head, dim3(1), dim3(1024), 0, s, st, pass & 1u, head, q0, q1, st->level_count, ref_base, leaf_tag, remap, children,
-                                 leaf_boxes, order, node_boxes, nodes_out);
+    const uint32_t width = wide6 ? 6u : 4u;
+    const uint32_t allowed = std::min<uint32_t>(stack_capacity / (width - 1), kMaxLevels - 1);  // levels the traversal stack can hold (width - 1 pushes per level)
+    const uint32_t head = std::min(wide6 ? 4u : kHeadLevels, allowed);                          // width^(head - 1) <= 1 024
+    auto grow = [&](uint32_t b) { return b > n / width ? n : b * width; };
+    if (head) {
+      if (wide6) hipLaunchKernelGGL(k_emit_sah_head<true>, dim3(1), dim3(1024), 0, s, st, pass & 1u, head, q0, q1, st->level_count, ref_base, leaf_tag, remap, children,
+                                    leaf_boxes, order, node_boxes, tri_perm, nodes_out);
+      else hipLaunchKernelGGL(k_emit_sah_head<false>, dim3(1), dim3(1024), 0, s, st, pass & 1u, head, q0, q1, st->level_count, ref_base, leaf_tag, remap, children,
+                              leaf_boxes, order, node_boxes, tri_perm, nodes_out);
+    }
     level = head;
-    for (uint32_t l = 0; l < head; l++) level_bound = level_bound > n / 4 ? n : level_bound * 4;
-    uint32_t batch = (uint32_t)std::ceil(std::log((double)n) / std::log(4.0)) + 8;
+    for (uint32_t l = 0; l < head; l++) level_bound = grow(level_bound);
+    uint32_t batch = (uint32_t)std::ceil(std::log((double)n) / std::log((double)width)) + 8;
     batch = batch > head ? batch - head : 1;
     while (!finished) {
       for (uint32_t k = 0; k < batch && level < allowed; k++, level++) {
-        hipLaunchKernelGGL(k_emit_sah_dev, dim3((level_bound + 255) / 256), dim3(256), 0, s, st, pass & 1u, level, (level & 1u) ? q1 : q0, (level & 1u) ? q0 : q1,
-                           st->level_count, ref_base, leaf_tag, remap, children, leaf_boxes, order, node_boxes, nodes_out);
-        level_bound = level_bound > n / 4 ? n : level_bound * 4;
+        if (wide6) hipLaunchKernelGGL(k_emit_sah_dev<true>, dim3((level_bound + 255) / 256), dim3(256), 0, s, st, pass & 1u, level, (level & 1u) ? q1 : q0,
+                                      (level & 1u) ? q0 : q1, st->level_count, ref_base, leaf_tag, remap, children, leaf_boxes, order, node_boxes, tri_perm, nodes_out);
+        else hipLaunchKernelGGL(k_emit_sah_dev<false>, dim3((level_bound + 255) / 256), dim3(256), 0, s, st, pass & 1u, level, (level & 1u) ? q1 : q0,
+                                (level & 1u) ? q0 : q1, st->level_count, ref_base, leaf_tag, remap, children, leaf_boxes, order, node_boxes, tri_perm, nodes_out);
+        level_bound = grow(level_bound);
       }
       batch = 6;
       LB_CHECK(hipMemcpyAsync(&h, st, sizeof(BuildState), hipMemcpyDeviceToHost, s));
@@ -831,6 +905,7 @@ static hipError_t build_dev(hipStream_t s, uint32_t n, const Box* leaf_boxes, co
         level_bound = std::min<uint64_t>((uint64_t)h.level_count[level - 1], (uint64_t)n);  // the next level's real size
       }
     }
+    if (wide6 && h.leaf_count != n) goto done;  // (every triangle gets exactly one slot)
   }
   if (total >= 1 && total <= n - 1) {
     *ok = true;
@@ -843,7 +918,7 @@ done:
 }
 
 // ---- one tree ------------------------------------------------------------------------------------------------------------
-struct TreeInfo { uint32_t root_ref = kInvalidRef, node_span = 0, depth4 = 0; };
+struct TreeInfo { uint32_t root_ref = kInvalidRef, node_span = 0, depth4 = 0; bool wide6 = false; };
 
 // A 4-wide quantised BVH over n >= 1 leaf boxes (device memory), written at nodes_out[0 .. node_span): Morton order (rocPRIM
 // radix sort) -> PLOC binary tree (Karras radix tree as the fallback) -> SAH-guided 4-wide collapse, dense in BFS order.
@@ -867,8 +942,11 @@ static hipError_t tree_arena_bytes(uint32_t n, size_t* sort_bytes_out, size_t* s
   return hipSuccess;
 }
 // (`scratch`: tree_arena_bytes(n) bytes of device memory, the caller's)
+// `tri_perm_out` != nullptr asks for the 6-wide form (BvhNode6: ref_base 0, no remap): info->wide6 says whether it was built (only the
+// device-driven PLOC path builds it; the fallbacks give the 4-wide form) — tri_perm_out[slot] = position in the Morton order.
 static hipError_t build_tree(hipStream_t s, uint32_t n, const Box* leaf_boxes, uint32_t stack_capacity, bool use_ploc, BvhNode* nodes_out,
-                             uint32_t ref_base, uint32_t leaf_tag, bool remap, uint32_t* order_out, char* scratch, size_t scratch_bytes, TreeInfo* info) {
+                             uint32_t ref_base, uint32_t leaf_tag, bool remap, uint32_t* order_out, uint32_t* tri_perm_out, char* scratch,
+                             size_t scratch_bytes, TreeInfo* info) {
   hipError_t err = hipSuccess;
   *info = TreeInfo{};
   const uint32_t blocks = (n + 255) / 256;
@@ -913,8 +991,13 @@ static hipError_t build_tree(hipStream_t s, uint32_t n, const Box* leaf_boxes, u
       // PLOC + collapse without host round trips; anything it cannot finish (pass limit, a tree deeper than the stack) goes the old way
       bool ok = false;
       uint32_t emitted = 0, levels = 0;
+      const bool wide6 = tri_perm_out != nullptr && n >= 2 && n < kMaxWide6Triangles && getenv("PTAMD_BVH4") == nullptr;
       LB_CHECK(build_dev(s, n, leaf_boxes, vals_b, stack_capacity, children, node_boxes, queue[0], queue[1], ref_base, leaf_tag, remap ? 1u : 0u,
-                          nodes_out, arena, &ok, &emitted, &levels));
+                          nodes_out, wide6, tri_perm_out, arena, &ok, &emitted, &levels));
+      if (!ok && wide6) {  // (e.g. deeper than the stack at five pushes per level: the 4-wide form needs three)
+        LB_CHECK(build_dev(s, n, leaf_boxes, vals_b, stack_capacity, children, node_boxes, queue[0], queue[1], ref_base, leaf_tag, remap ? 1u : 0u,
+                            nodes_out, false, nullptr, arena, &ok, &emitted, &levels));
+      } else if (ok) info->wide6 = wide6;
       if (ok) {
         info->root_ref = ref_base + 0u;
         if (order_out) LB_CHECK(hipMemcpyAsync(order_out, vals_b, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, s));
@@ -1009,7 +1092,7 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
   hipError_t err = hipSuccess;
   const uint32_t n = tri_count;
   const uint32_t blocks = (n + 255) / 256;
-  TriRec* tris_tmp = nullptr; Box* leaf_boxes = nullptr; BvhNode* nodes_tmp = nullptr; uint32_t* order = nullptr;
+  TriRec* tris_tmp = nullptr; Box* leaf_boxes = nullptr; BvhNode* nodes_tmp = nullptr; uint32_t *order = nullptr, *tri_perm = nullptr;
   TreeInfo info;
   const bool use_ploc = getenv("PTAMD_RADIX_TREE") == nullptr;  // PLOC by default; the Karras radix tree is the fallback
 
@@ -1017,19 +1100,21 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
   size_t tree_bytes = 0;
   char* tree_scratch = nullptr;
   LB_CHECK(tree_arena_bytes(n, nullptr, nullptr, &tree_bytes));
-  tmp.cap = Arena::pad(sizeof(TriRec) * (size_t)n) + Arena::pad(sizeof(Box) * (size_t)n) + Arena::pad(sizeof(uint32_t) * (size_t)n) +
+  tmp.cap = Arena::pad(sizeof(TriRec) * (size_t)n) + Arena::pad(sizeof(Box) * (size_t)n) + 2 * Arena::pad(sizeof(uint32_t) * (size_t)n) +
             Arena::pad(sizeof(BvhNode) * (size_t)(n > 1 ? n - 1 : 1)) + Arena::pad(tree_bytes);
   LB_CHECK(scratch->ensure(tmp.cap));
   tmp.base = scratch->base;
   tris_tmp = tmp.take<TriRec>(n);
   leaf_boxes = tmp.take<Box>(n);
   order = tmp.take<uint32_t>(n);
+  tri_perm = tmp.take<uint32_t>(n);
   nodes_tmp = tmp.take<BvhNode>(n > 1 ? n - 1 : 1);
   tree_scratch = tmp.take<char>(tree_bytes);
   LB_CHECK(hipMalloc(&out->tris, sizeof(TriRec) * (size_t)n));
   hipLaunchKernelGGL(k_flatten, dim3(blocks), dim3(256), 0, s, S, instance_count, n, tris_tmp, leaf_boxes);
-  LB_CHECK(build_tree(s, n, leaf_boxes, stack_capacity, use_ploc, nodes_tmp, 0u, kLeafBit, false, order, tree_scratch, tree_bytes, &info));
-  hipLaunchKernelGGL(k_reorder_tris, dim3(blocks), dim3(256), 0, s, (int)n, order, tris_tmp, out->tris);  // triangles in leaf (Morton) order
+  LB_CHECK(build_tree(s, n, leaf_boxes, stack_capacity, use_ploc, nodes_tmp, 0u, kLeafBit, false, order, tri_perm, tree_scratch, tree_bytes, &info));
+  if (info.wide6) hipLaunchKernelGGL(k_reorder_tris6, dim3(blocks), dim3(256), 0, s, (int)n, tri_perm, order, tris_tmp, out->tris);  // triangles in the collapse's leaf numbering
+  else hipLaunchKernelGGL(k_reorder_tris, dim3(blocks), dim3(256), 0, s, (int)n, order, tris_tmp, out->tris);  // triangles in leaf (Morton) order
   if (info.node_span) {  // keep exactly the records the tree uses
     LB_CHECK(hipMalloc(&out->nodes, sizeof(BvhNode) * (size_t)info.node_span));
     LB_CHECK(hipMemcpyAsync(out->nodes, nodes_tmp, sizeof(BvhNode) * (size_t)info.node_span, hipMemcpyDeviceToDevice, s));
@@ -1039,6 +1124,7 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
   out->root_ref = info.root_ref;
   out->node_count = info.node_span;
   out->depth4 = info.depth4;
+  out->wide6 = info.wide6;
 
 done:
   if (err != hipSuccess) {
@@ -1144,14 +1230,14 @@ hipError_t build_two_level(hipStream_t s, const DeviceScene& S, const MeshInfo* 
   // world-space triangles in flattening order (the intersection contract's triangles) and the instances' world boxes
   hipLaunchKernelGGL(k_flatten, dim3((tri_count + 255) / 256), dim3(256), 0, s, S, instance_count, tri_count, out->tris, tri_boxes);
   hipLaunchKernelGGL(k_instance_boxes, dim3(instance_count), dim3(256), 0, s, S, tri_boxes, inst_boxes);
-  LB_CHECK(build_tree(s, instance_count, inst_boxes, stack_capacity, use_ploc, nodes_tmp, 0u, kInstBit, true, nullptr, tree_scratch, tree_bytes, &tlas));
+  LB_CHECK(build_tree(s, instance_count, inst_boxes, stack_capacity, use_ploc, nodes_tmp, 0u, kInstBit, true, nullptr, nullptr, tree_scratch, tree_bytes, &tlas));
   base = tlas.node_span;
   for (uint32_t m = 0; m < mesh_count; m++) {
     const MeshInfo mesh = meshes[m];
     if (mesh.tri_count == 0) { mt[m].root_ref = kInvalidRef; continue; }
     TreeInfo blas;
     hipLaunchKernelGGL(k_mesh_boxes, dim3((mesh.tri_count + 255) / 256), dim3(256), 0, s, S, mesh, mesh_boxes);
-    LB_CHECK(build_tree(s, mesh.tri_count, mesh_boxes, stack_capacity, use_ploc, nodes_tmp + base, base, kLeafBit, true, nullptr, tree_scratch, tree_bytes, &blas));
+    LB_CHECK(build_tree(s, mesh.tri_count, mesh_boxes, stack_capacity, use_ploc, nodes_tmp + base, base, kLeafBit, true, nullptr, nullptr, tree_scratch, tree_bytes, &blas));
     LB_CHECK(hipMemcpyAsync(&out->mesh_trav[m].root_ref, &blas.root_ref, sizeof(uint32_t), hipMemcpyHostToDevice, s));
     if (blas.node_span) hipLaunchKernelGGL(k_root_bounds, dim3(1), dim3(1), 0, s, nodes_tmp + base, out->mesh_trav + m);
     else hipLaunchKernelGGL(k_box_bounds, dim3(1), dim3(1), 0, s, mesh_boxes, out->mesh_trav + m);

@@ -381,13 +381,14 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
     (void)hipEventElapsedTime(&ms, ev.e0, ev.e1);
     r->bvh_ms = ms;
     // traversal stack: <= 3 pushes per 4-wide level; 4-wide depth = ceil(binary depth / 2)
-    if (r->bvh.depth4 * 3 + (r->two_level ? 1 : 0) > (uint32_t)(kLdsStack + kSpillStack))
+    if (r->bvh.depth4 * (r->bvh.wide6 ? 5u : 3u) + (r->two_level ? 1 : 0) > (uint32_t)(kLdsStack + kSpillStack))
       return fail(PT_ERR_UNSUPPORTED, "BVH too deep for the traversal stack (degenerate geometry: thousands of coincident triangles?)");
     S.nodes = r->bvh.nodes;
     S.tris = r->bvh.tris;
     S.root_ref = r->bvh.root_ref;
     S.node_count = r->bvh.node_count;
     S.two_level = r->two_level ? 1u : 0u;
+    S.wide6 = r->bvh.wide6 ? 1u : 0u;
     S.inst_trav = r->inst_trav.p;
     S.mesh_trav = r->bvh.mesh_trav;
   }

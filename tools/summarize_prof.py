@@ -25,10 +25,10 @@ KEYS = ("k_shade", "k_raygen", "k_accumulate", "k_fold_counters", "k_chunk_table
 
 
 def short(name):
-    """k_trace_closest<COUNT, TWO>: the render instantiation of the one-BVH kernel is the bare name; the instrumented and the
-    two-level instantiations are tagged."""
+    """k_trace_closest<COUNT, TWO, W6>: the render instantiation of the one-BVH kernel (4- or 6-wide nodes: whichever the build produced) is
+    the bare name; the instrumented and the two-level instantiations are tagged."""
     import re
-    m = re.search(r"(k_trace_closest|k_trace_shadow)<(?:\(bool\))?(\w+), (?:\(bool\))?(\w+)>", name)
+    m = re.search(r"(k_trace_closest|k_trace_shadow)<(?:\(bool\))?(\w+), (?:\(bool\))?(\w+)(?:, (?:\(bool\))?(\w+))?>", name)
     if m:
         count, two = m.group(2) in ("true", "1"), m.group(3) in ("true", "1")
         return m.group(1) + ("[count]" if count else "") + ("[two-level]" if two else "")
