@@ -283,6 +283,9 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DeviceScene S, PathState st, 
 #endif
 constexpr uint32_t kTraceBlock2 = PT_TWO_BLOCK;  // two-level kernels: ONE block per CU (4 waves per SIMD) sharing the staged node array
 constexpr uint32_t kLdsNodes = PT_TWO_LDS_NODES; // 64 KB of nodes in LDS beside the 88 KB of stacks and leaf queues of 1024 lanes (152 of 160 KB)
+#ifndef PT_TRI_VOTE
+#define PT_TRI_VOTE 2
+#endif
 template <bool ANY, bool COUNT, bool TWO, bool W6 = false>
 __device__ __forceinline__ void wave_traverse(const DeviceScene& S, const BvhNode* lds_nodes, TravState& ts, TraversalCount* tc) {
   // room a node step needs in the lane's leaf queue: one entry per child it can queue (4-wide), one entry per node (6-wide: a range)
@@ -312,7 +315,7 @@ __device__ __forceinline__ void wave_traverse(const DeviceScene& S, const BvhNod
   const unsigned long long mp = __ballot(pending);
   if (mp == 0) return;
   // triangle round when half of the lanes holding a ray have a queued leaf, a lane's queue is full, or nobody can advance
-  const bool go = 2 * __popcll(mp) >= __popcll(__ballot(1)) || __ballot(ts.st.npend > kRows - kRoom) != 0 || __ballot(advancing) == 0;
+  const bool go = PT_TRI_VOTE * __popcll(mp) >= __popcll(__ballot(1)) || __ballot(ts.st.npend > kRows - kRoom) != 0 || __ballot(advancing) == 0;
   if (go && pending) {
     const bool fin = W6 ? trav_pending_leaf6<ANY, COUNT>(S, ts, tc) : trav_pending_leaf<ANY, COUNT>(S, ts, tc);
     if (fin) { ts.cur = kInvalidRef; ts.st.npend = 0; ts.st.sp = 0; }

@@ -518,6 +518,12 @@ PT_HD bool trav_pending_leaf(const DeviceScene& S, TravState& ts, TraversalCount
 // scheduling in kernels.hip — the answer does not depend on the order in which candidates are tested).
 template <bool ANY, bool COUNT>
 PT_HD bool trav_step(const DeviceScene& S, TravState& ts, TraversalCount* cnt) {
+  if (S.wide6) {
+    trav_node6<COUNT>(S.nodes, ts, cnt);
+    while (ts.st.npend > 0)
+      if (trav_pending_leaf6<ANY, COUNT>(S, ts, cnt)) return true;
+    return ts.cur == kInvalidRef;
+  }
   trav_node<COUNT>(S.nodes, ts, cnt);
   while (ts.st.npend > 0)
     if (trav_pending_leaf<ANY, COUNT>(S, ts, cnt)) return true;

@@ -112,6 +112,36 @@ void collapse_sah(Emu& e, const std::vector<BinNode>& bin, const std::vector<uin
   for (int k = 0; k < count; k++) if (!(refs[k] & kLeafBit)) collapse_sah(e, bin, order, boxes, refs[k]);
 }
 
+// EMU_WIDE6=1: the product's 6-wide form (BvhNode6, lbvh.hip emit_sah_node6): open the child with the largest surface area until six slots
+// are used, internal children first; a node's internal children get consecutive records and its leaf children consecutive triangle slots
+// (tri_perm[slot] = position in `order`).  Depth-first here (the GPU numbers level by level): the traversal only needs the two properties.
+void collapse6(Emu& e, const std::vector<BinNode>& bin, const std::vector<uint32_t>& order, const std::vector<Box3>& boxes, uint32_t i, uint32_t dense,
+               std::vector<uint32_t>& tri_perm) {
+  uint32_t refs[6] = {bin[i].left, bin[i].right, 0, 0, 0, 0}; int count = 2;
+  auto box_of = [&](uint32_t ref) { return (ref & kLeafBit) ? boxes[order[ref & ~kLeafBit]] : bin[ref].box; };
+  while (count < 6) {
+    int best = -1; float ba = -1.0f;
+    for (int k = 0; k < count; k++) if (!(refs[k] & kLeafBit)) { const float a = half_area(box_of(refs[k])); if (a > ba) { ba = a; best = k; } }
+    if (best < 0) break;
+    const uint32_t r = refs[best];
+    refs[best] = bin[r].left; refs[count++] = bin[r].right;
+  }
+  uint32_t ints[6], n_int = 0, n_leaf = 0;
+  Box3 bi[6], bl[6], bx[6];
+  const uint32_t base_leaf = (uint32_t)tri_perm.size();
+  for (int k = 0; k < count; k++) {
+    if (refs[k] & kLeafBit) { bl[n_leaf++] = inflate_box(box_of(refs[k])); tri_perm.push_back(refs[k] & ~kLeafBit); }
+    else { bi[n_int] = inflate_box(box_of(refs[k])); ints[n_int++] = refs[k]; }
+  }
+  for (uint32_t k = 0; k < n_int; k++) bx[k] = bi[k];
+  for (uint32_t k = 0; k < n_leaf; k++) bx[n_int + k] = bl[k];
+  const uint32_t base_node = (uint32_t)e.nodes.size();
+  e.nodes.resize(e.nodes.size() + n_int);
+  const BvhNode6 n6 = quantize_node6(bx, (int)n_int, (int)n_leaf, base_node, base_leaf);
+  memcpy(&e.nodes[dense], &n6, sizeof(n6));
+  for (uint32_t k = 0; k < n_int; k++) collapse6(e, bin, order, boxes, ints[k], base_node + k, tri_perm);
+}
+
 // EMU_SAH_BUILD=1: top-down binned-SAH builder (16 bins, centroid bounds) — a quality yardstick for the GPU's Morton tree
 uint32_t build_sah(std::vector<BinNode>& bin, std::vector<uint32_t>& order, const std::vector<Box3>& boxes, uint32_t first, uint32_t count) {
   if (count == 1) return kLeafBit | first;
@@ -386,6 +416,8 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
   std::vector<uint32_t> order(tmp.size());
   for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
   uint32_t root = kInvalidRef;
+  bool wide6 = false;
+  std::vector<uint32_t> tri_perm;
   if (!tmp.empty()) {
     std::vector<BinNode> bin;
     if (getenv("EMU_MORTON")) {
@@ -406,7 +438,13 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
       else root = build_morton(bin, order, keys, boxes, 0, (uint32_t)tmp.size());
     } else if (getenv("EMU_SAH_BUILD")) root = build_sah(bin, order, boxes, 0, (uint32_t)tmp.size());
     else root = build_bin(bin, order, boxes, 0, (uint32_t)tmp.size());
-    if (!(root & kLeafBit)) {
+    if (!(root & kLeafBit) && getenv("EMU_WIDE6")) {
+      e->nodes.assign(1, BvhNode{});
+      e->nodes.reserve(bin.size());
+      collapse6(*e, bin, order, boxes, root, 0u, tri_perm);
+      root = 0u;
+      wide6 = true;
+    } else if (!(root & kLeafBit)) {
       e->nodes.assign(bin.size(), BvhNode{});
       if (getenv("EMU_SAH_COLLAPSE")) collapse_sah(*e, bin, order, boxes, root); else collapse(*e, bin, order, boxes, root);
       if (getenv("EMU_WIDE_PROBE")) {
@@ -428,14 +466,14 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
     }
   }
   e->tris.resize(tmp.size());
-  for (size_t i = 0; i < order.size(); i++) e->tris[i] = tmp[order[i]];
+  for (size_t i = 0; i < order.size(); i++) e->tris[i] = tmp[order[wide6 ? tri_perm[i] : i]];
 
   DeviceScene& S = e->S;
   memset(&S, 0, sizeof(S));
   S.positions = e->hs.positions.data(); S.vdata = e->hs.vdata.data(); S.indices = e->hs.indices.data(); S.slots = e->hs.slots.data();
   S.meshes = e->hs.meshes.data(); S.instances = e->hs.instances.data(); S.materials = e->hs.materials.data();
   S.lights = e->hs.lights.data(); S.nodes = e->nodes.data(); S.tris = e->tris.data(); S.tri_count = (uint32_t)e->tris.size();
-  S.root_ref = root; S.halton = e->halton.data();
+  S.root_ref = root; S.wide6 = wide6 ? 1u : 0u; S.halton = e->halton.data();
   e->shade_recs.resize(e->tris.size());
   for (size_t i = 0; i < e->tris.size(); i++) e->shade_recs[i] = make_shade_rec(S, e->tris[i]);
   S.shade_recs = e->shade_recs.data();
@@ -529,7 +567,7 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
   const DeviceScene& S = e->S;
   const uint32_t W = S.width, H = S.height, B = S.max_bounces, NP = W * H;
   if (hits) for (size_t i = 0; i < (size_t)B * NP * 2; i++) hits[i] = -1;
-  std::vector<uint32_t> lds(kLdsStack + 1), spill(kSpillStack), pend(kPendLeaves + 1);
+  std::vector<uint32_t> lds(std::max(kLdsStack, kLdsStack6) + 1), spill(kSpillStack), pend(std::max(kPendLeaves, kPendLeaves6) + 1);
   for (uint32_t y = 0; y < H; y++)
     for (uint32_t x = 0; x < W; x++) {
       const uint32_t pid = y * W + x;
@@ -587,7 +625,7 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
 void emu_trace_primary(void* h, uint32_t sample, pt_hit_record* out) {
   Emu* e = (Emu*)h;
   const DeviceScene& S = e->S;
-  std::vector<uint32_t> lds(kLdsStack + 1), spill(kSpillStack), pend(kPendLeaves + 1);
+  std::vector<uint32_t> lds(std::max(kLdsStack, kLdsStack6) + 1), spill(kSpillStack), pend(std::max(kPendLeaves, kPendLeaves6) + 1);
   for (uint32_t y = 0; y < S.height; y++)
     for (uint32_t x = 0; x < S.width; x++) {
       RayGenOut rg = stage_raygen(S, x, y, sample);
@@ -608,7 +646,7 @@ void emu_trace_primary(void* h, uint32_t sample, pt_hit_record* out) {
 void emu_packet_probe(void* h, uint32_t sample, double out[6]) {
   Emu* e = (Emu*)h;
   const DeviceScene& S = e->S;
-  std::vector<uint32_t> lds(kLdsStack + 1), spill(kSpillStack), pend(kPendLeaves + 1);
+  std::vector<uint32_t> lds(std::max(kLdsStack, kLdsStack6) + 1), spill(kSpillStack), pend(std::max(kPendLeaves, kPendLeaves6) + 1);
   double packets = 0, pn = 0, pt_ = 0, rn = 0, rt = 0, mism = 0;
   for (uint32_t ty = 0; ty < (S.height + 7) / 8; ty++)
     for (uint32_t tx = 0; tx < (S.width + 7) / 8; tx++) {

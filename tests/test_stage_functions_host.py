@@ -69,6 +69,25 @@ def test_random_scene_fuzz_stage_functions(seed):
     assert np.array_equal(ro.view(np.uint32)[~nan], re_.view(np.uint32)[~nan])
 
 
+@pytest.mark.parametrize("name", ["cornell_sphere", "field3", "random5", "random11", "textured"])
+def test_six_wide_nodes_give_the_same_hits_and_radiance(name, monkeypatch):
+    """r03: the one-BVH structure's 6-wide node form (pt_device.h BvhNode6: quantize_node6 / trav_node6 / the range entries of the leaf
+    queue in pt_bvh.h) through the host harness, which builds it with the two properties the GPU builder gives it — a node's internal
+    children are consecutive records, its leaf children consecutive triangles — against the oracle: the hits and the radiance do not
+    depend on the structure that was walked (the GPU side of this is every `-m gpu` parity test: the device build is 6-wide by default)."""
+    monkeypatch.setenv("EMU_WIDE6", "1")
+    sc = {"cornell_sphere": scenes.cornell_sphere_scene, "field3": lambda: scenes.field_scene(3), "random5": lambda: scenes.random_scene(5),
+          "random11": lambda: scenes.random_scene(11), "textured": lambda: scenes.textured_scene()}[name]()
+    p = make_params(64, 36, 1, 6)
+    o, e = oracle_lib.OracleScene(sc, p), emu_lib.EmuScene(sc, p)
+    assert o.trace_primary(1).tobytes() == e.trace_primary(1).tobytes()
+    ro, ho = o.debug_sample(0)
+    re_, he = e.debug_sample(0)
+    nan = np.isnan(ro)
+    assert np.array_equal(ho, he) and np.array_equal(nan, np.isnan(re_))
+    assert np.array_equal(ro.view(np.uint32)[~nan], re_.view(np.uint32)[~nan])
+
+
 def test_halton_fp32_division_boundaries_equal_oracle():
     """The strength-reduced radical inverse of pt_sampler.h at the multiples of every dimension's chunk (+-1), around 2^21 and at
     the top of the 32-bit range.  (An fp32 division of the small quotients was tried on top of it: bit-exact, but slower.)"""
