@@ -534,6 +534,30 @@ def test_two_level_structure_gives_the_same_hits_and_radiance(gpu_renderer, whic
         assert gpu_renderer.stats().bvh_nodes < 700
 
 
+@pytest.mark.parametrize("which", ["field", "fuzz", "textured"])
+def test_four_wide_fallback_form_gives_the_same_hits_and_radiance(gpu_renderer, which, monkeypatch):
+    """r03: the device build emits 6-wide nodes (BvhNode6) by default — every other test in this file runs on them.  $PTAMD_BVH4 keeps the
+    4-wide form (what the fallback builders — radix tree, per-pass launches, trees deeper than the stack at five pushes per level — and the
+    two-level structure use); it must give the oracle's answers too, from a tree with more nodes."""
+    cases = {"field": [scenes.field_scene(8)], "fuzz": [scenes.random_scene(s) for s in (3, 7, 11, 19)], "textured": [scenes.textured_scene()]}[which]
+    for sc in cases:
+        w, h, bounces = 128, 72, 6
+        gpu_renderer.selectKernel(abi.INTEGRATOR_MIS)
+        gpu_renderer.startRender(sc, (w, h), 2, max_bounces=bounces)
+        nodes6 = gpu_renderer.stats().bvh_nodes
+        monkeypatch.setenv("PTAMD_BVH4", "1")
+        gpu_renderer.startRender(sc, (w, h), 2, max_bounces=bounces)
+        monkeypatch.delenv("PTAMD_BVH4")
+        assert gpu_renderer.stats().bvh_nodes > nodes6
+        o = oracle_lib.OracleScene(sc, make_params(w, h, 2, bounces))
+        assert gpu_renderer.tracePrimary(0).tobytes() == o.trace_primary(0).tobytes()
+        rg, hg = gpu_renderer.debugSample(0)
+        rc, hc = o.debug_sample(0)
+        assert np.array_equal(hg, hc) and _same_bits_or_both_nan(rg, rc)
+        gpu_renderer.render(0)
+        assert _same_bits_or_both_nan(gpu_renderer.readbackAccumulator(), o.render(0, 2))
+
+
 def _same_bits_or_both_nan(a, b):
     """Bitwise equality, except that NaNs only have to coincide: x86 and gfx950 produce default NaNs of opposite sign."""
     nan = np.isnan(a)
