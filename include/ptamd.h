@@ -392,7 +392,8 @@ int pt_debug_sample(pt_renderer* r, uint32_t sample_idx, float* radiance_out, in
 typedef struct pt_stats {
   uint64_t triangles;          /* flattened world-space triangles */
   uint64_t bvh_nodes;
-  uint32_t bvh_max_depth;      /* levels of the 4-wide tree (two-level: TLAS + deepest BLAS); the traversal stack holds <= 3 entries per level */
+  uint32_t bvh_max_depth;      /* levels of the tree (two-level: TLAS + deepest BLAS); the traversal stack holds <= 5 entries per level of the
+                                  6-wide form the one-BVH structure is built in by default, <= 3 of the 4-wide form ($PTAMD_BVH4, the fallback builders) */
   uint32_t samples_in_flight;
   double upload_ms;            /* snapshot -> HBM */
   double bvh_build_ms;         /* LBVH build (device time) */
