@@ -247,6 +247,9 @@ def main():
         import ctypes as _C
         plan = abi.QueuePlan()
         free_b, _tot = torch.cuda.mem_get_info(local_rank)
+        if args.inproc and args.devices:  # logical shards that share a device share its memory
+            _d = [int(x) for x in args.devices.split(",")]
+            free_b //= max(_d.count(x) for x in set(_d))
         abi.check(abi.load_library(), abi.load_library().pt_plan_queues(W, H, 1 << 20, 0, int(free_b), 0, 4, _C.byref(plan)))
         S = int(plan.samples_in_flight)
     ndev_all = args.gpus if (args.inproc and args.gpus > 1) else world
