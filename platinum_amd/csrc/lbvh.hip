@@ -872,7 +872,9 @@ static hipError_t build_dev(hipStream_t s, uint32_t n, const Box* leaf_boxes, co
   hipLaunchKernelGGL(k_seed_queue, dim3(1), dim3(1), 0, s, q0, counts, n - 2);
   {
     const uint32_t width = wide6 ? 6u : 4u;
-    const uint32_t allowed = std::min<uint32_t>(stack_capacity / (width - 1), kMaxLevels - 1);  // levels the traversal stack can hold (width - 1 pushes per level)
+    uint32_t allowed = std::min<uint32_t>(stack_capacity / (width - 1), kMaxLevels - 1);  // levels the traversal stack can hold (width - 1 pushes per level)
+    if (wide6) if (const char* e = getenv("PTAMD_TEST_W6_LEVELS")) allowed = std::min<uint32_t>(allowed, (uint32_t)std::max(1, atoi(e)));  // test hook: makes the 6-wide
+                                                                                         // form "too deep" so that the retry in the 4-wide form runs (tests/test_gpu_parity.py)
     const uint32_t head = std::min(wide6 ? 4u : kHeadLevels, allowed);                          // width^(head - 1) <= 1 024
     auto grow = [&](uint32_t b) { return b > n / width ? n : b * width; };
     if (head) {

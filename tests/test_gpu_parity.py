@@ -558,6 +558,26 @@ def test_four_wide_fallback_form_gives_the_same_hits_and_radiance(gpu_renderer, 
         assert _same_bits_or_both_nan(gpu_renderer.readbackAccumulator(), o.render(0, 2))
 
 
+def test_six_wide_tree_deeper_than_the_stack_is_rebuilt_four_wide(gpu_renderer, monkeypatch):
+    """A tree deeper than the traversal stack holds at five pushes per level must come back in the 4-wide form (three per level) from the
+    same build call.  No test scene is that deep, so $PTAMD_TEST_W6_LEVELS lowers the 6-wide limit: the retry path runs for real."""
+    sc = scenes.field_scene(8)
+    w, h, bounces = 96, 54, 5
+    gpu_renderer.selectKernel(abi.INTEGRATOR_MIS)
+    monkeypatch.setenv("PTAMD_BVH4", "1")
+    gpu_renderer.startRender(sc, (w, h), 1, max_bounces=bounces)
+    nodes4 = gpu_renderer.stats().bvh_nodes
+    monkeypatch.delenv("PTAMD_BVH4")
+    monkeypatch.setenv("PTAMD_TEST_W6_LEVELS", "3")
+    gpu_renderer.startRender(sc, (w, h), 1, max_bounces=bounces)
+    monkeypatch.delenv("PTAMD_TEST_W6_LEVELS")
+    assert gpu_renderer.stats().bvh_nodes == nodes4          # the 4-wide tree, not a truncated 6-wide one
+    o = oracle_lib.OracleScene(sc, make_params(w, h, 1, bounces))
+    rg, hg = gpu_renderer.debugSample(0)
+    rc, hc = o.debug_sample(0)
+    assert np.array_equal(hg, hc) and _same_bits_or_both_nan(rg, rc)
+
+
 def _same_bits_or_both_nan(a, b):
     """Bitwise equality, except that NaNs only have to coincide: x86 and gfx950 produce default NaNs of opposite sign."""
     nan = np.isnan(a)
