@@ -341,6 +341,11 @@ def main():
     r.setProfiling(False)
     elapsed = timed_pass()
     st = r.stats()
+    # the batch the library actually traced (it plans again at start, against the memory left after the scene and the accumulator): a step
+    # is only "one batch" when that equals S - otherwise say so instead of labelling several batches as one step
+    S_lib = int(st.samples_in_flight)
+    if S_lib != S and rank == 0:
+        print("bench.py: the library runs %d samples in flight, not the %d a step asks for: one step = %d batches" % (S_lib, S, -(-S // max(1, S_lib))), file=sys.stderr)
     spp_all = total_spp * (1 if inproc else world)   # samples per pixel the whole job accumulated in the timed region
     value = W * H * spp_all * B / elapsed / 1e6
     mean_radiance = float(acc[..., :3].mean().item())
@@ -356,6 +361,10 @@ def main():
 
     lib_sha = library_sha16()
     pmc, pmc_src = load_pmc_profile(args.workload)
+    if rank == 0 and pmc is not None:
+        stale = bool(lib_sha and pmc.get("library_sha16") and pmc["library_sha16"] != lib_sha)
+        print("bench.py: counter figures from %s (taken on library %s; this library %s%s)" % (pmc_src, pmc.get("library_sha16"), lib_sha,
+              " - STALE: the roofline's counter bytes are NOT of this build, re-run tools/profile_round.sh" if stale else ""), file=sys.stderr)
     blocks = {}
     if ks.ms_closest > 0:
         blocks["k_trace_closest"] = kernel_block(
@@ -393,7 +402,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": WORKLOADS[args.workload],
-            "width": W, "height": H, "max_bounces": B, "spp_per_step": S, "spp_per_gpu": total_spp // ndev, "spp_total": spp_all,
+            "width": W, "height": H, "max_bounces": B, "spp_per_step": S, "samples_in_flight": S_lib, "batches_per_step": -(-S // max(1, S_lib)), "spp_per_gpu": total_spp // ndev, "spp_total": spp_all,
             "integrator": "MIS+NEE", "flags": "MultiscatterGGX", "triangles": int(st.triangles),
             "call_pattern": "render(1) per call, merged by the library (reference frontend loop)" if args.drop_in_loop else "render(spp_per_step) per step",
             "batches": int(st.batches),

@@ -54,7 +54,8 @@ typedef enum pt_error {
   PT_ERR_OUT_OF_MEMORY = -4,
   PT_ERR_BAD_STATE = -5,     /* e.g. pt_render_step before pt_start_render */
   PT_ERR_UNSUPPORTED = -6,   /* a scene feature that is not implemented */
-  PT_ERR_BAD_LUT = -7
+  PT_ERR_BAD_LUT = -7,
+  PT_ERR_RUNTIME_CONFLICT = -8 /* more than one HIP / HSA runtime mapped into the process (pt_get_runtime_info says which) */
 } pt_error;
 
 /* ---------------------------------------------------------------------------------------------------------- */
@@ -231,6 +232,19 @@ typedef struct pt_create_info {
 } pt_create_info;
 
 int pt_create(const pt_create_info* info, pt_renderer** out);
+/* Which GPU runtime objects this process holds and which of them serves this library.  No counterpart in the reference (Metal is a
+ * system framework); needed here because PyTorch's ROCm wheel bundles private copies of libamdhip64 / libhsa-runtime64 / librccl
+ * that can end up mapped BESIDE the system's, and then only the runtime that initialises first sees the GPU.
+ * pt_create returns PT_ERR_RUNTIME_CONFLICT when hip_runtimes_mapped or hsa_runtimes_mapped exceeds 1.  Touches no GPU. */
+typedef struct pt_runtime_info {
+  char hip_runtime_path[512]; /* the libamdhip64 this library's hip* calls resolve to */
+  char hsa_runtime_path[512]; /* the (first) libhsa-runtime64 mapped */
+  char rccl_path[512];        /* the librccl bound by a device group / pt_rccl_probe; "" until one of them has loaded it */
+  uint32_t hip_runtimes_mapped, hsa_runtimes_mapped, rccl_mapped; /* distinct shared objects of each kind in the process */
+  int32_t hip_runtime_version; /* hipRuntimeGetVersion of the serving runtime, 0 if the call failed */
+  char all_mapped[2048];      /* every matching object, " + " separated: hip | hsa | rccl */
+} pt_runtime_info;
+int pt_get_runtime_info(pt_runtime_info* out);
 /* How a device group deals the samples [0, spp) of a render to its `members` (pure host arithmetic, exported for tests):
  * contiguous ranges, equal up to one sample; with PT_FLAG_GMON whole buckets per member (bucket b = samples
  * [b * ceil(spp / buckets), ...), renderer_pt.cpp:124-126), bucket0/bucket1 = each member's bucket range (may be NULL). */

@@ -185,6 +185,14 @@ class Stats(C.Structure):
     ]
 
 
+class RuntimeInfo(C.Structure):
+    _fields_ = [
+        ("hip_runtime_path", C.c_char * 512), ("hsa_runtime_path", C.c_char * 512), ("rccl_path", C.c_char * 512),
+        ("hip_runtimes_mapped", C.c_uint32), ("hsa_runtimes_mapped", C.c_uint32), ("rccl_mapped", C.c_uint32),
+        ("hip_runtime_version", C.c_int32), ("all_mapped", C.c_char * 2048),
+    ]
+
+
 assert C.sizeof(Float3) == 16 and C.sizeof(VertexData) == 48 and C.sizeof(MaterialGPU) == 96
 assert C.sizeof(Instance) == 64 and C.sizeof(CameraData) == 80 and C.sizeof(Constants) == 176
 assert C.sizeof(AreaLight) == 48
@@ -194,6 +202,7 @@ SYMBOLS = [
     ("pt_create", C.c_int, [C.POINTER(CreateInfo), C.POINTER(C.c_void_p)]),
     ("pt_group_partition", C.c_int, [C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("pt_get_runtime_info", C.c_int, [C.POINTER(RuntimeInfo)]),
     ("pt_rccl_probe", C.c_int, []),
     ("pt_rccl_selftest", C.c_int, [C.c_int32]),
     ("pt_plan_queues", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(QueuePlan)]),
@@ -241,22 +250,102 @@ def library_path():
     return os.environ.get("PTAMD_LIB", LIB_PATH)
 
 
+def _mapped_objects(prefix):
+    """Shared objects of this process whose file name starts with `prefix` (from /proc/self/maps)."""
+    found = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                parts = line.split(None, 5)
+                if len(parts) == 6 and os.path.basename(parts[5].strip()).startswith(prefix) and parts[5].strip() not in found:
+                    found.append(parts[5].strip())
+    except OSError:
+        pass
+    return found
+
+
+def _torch_bundled_hip():
+    """Path of the libamdhip64.so PyTorch's ROCm wheel bundles (torch/lib), found WITHOUT importing torch; None if there is none."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    for d in spec.submodule_search_locations:
+        p = os.path.join(d, "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def _settle_hip_runtime():
+    """Make sure the process ends up with ONE HIP runtime whichever of {libptamd.so, torch} arrives first.
+
+    Root cause (round 4): torch's wheel bundles libamdhip64.so / libhsa-runtime64.so / librccl.so with the same SONAMEs
+    as /opt/rocm's but links them by their unversioned file names through RPATH $ORIGIN.  torch first: libptamd.so's DT_NEEDED
+    `libamdhip64.so.7` matches the soname of torch's loaded copy - one runtime.  libptamd.so first: /opt/rocm's copy is mapped, and a
+    later `import torch` maps ITS copy beside it (DT_NEEDED `libamdhip64.so` matches no loaded soname and $ORIGIN leads to a different
+    file): two HIP + two HSA runtimes, and the one that initialises second cannot acquire the GPU VM - torch reports "No HIP GPUs are
+    available".  So: when no HIP runtime is mapped yet and this interpreter HAS a torch with a bundled runtime, map that one first
+    (RTLD_GLOBAL); libptamd.so then binds to it by soname and a later `import torch` finds the very file already loaded.
+    $PTAMD_HIP_RUNTIME=system keeps /opt/rocm's runtime instead (then torch must not be imported in this process);
+    the default `auto` does the above.  Returns a short description of what was done."""
+    mapped = _mapped_objects("libamdhip64.so")
+    if mapped:
+        return "already mapped: " + mapped[0]
+    mode = os.environ.get("PTAMD_HIP_RUNTIME", "auto")
+    if mode == "system":
+        return "system ($PTAMD_HIP_RUNTIME)"
+    if mode != "auto":
+        raise PtamdError(f"$PTAMD_HIP_RUNTIME={mode!r}: expected 'auto' or 'system'")
+    bundled = _torch_bundled_hip()
+    if bundled is None:
+        return "system (no torch with a bundled runtime in this interpreter)"
+    C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+    return "preloaded torch's bundled runtime: " + bundled
+
+
+_runtime_note = None
+
+
+def runtime_info(lib=None):
+    """pt_get_runtime_info as a dict (paths decoded) + how load_library() settled the HIP runtime."""
+    lib = lib or load_library()
+    ri = RuntimeInfo()
+    check(lib, lib.pt_get_runtime_info(C.byref(ri)))
+    d = {n: getattr(ri, n) for n, _ in RuntimeInfo._fields_}
+    for k, v in d.items():
+        if isinstance(v, bytes):
+            d[k] = v.decode()
+    d["settled"] = _runtime_note
+    return d
+
+
 def load_library(path=None):
-    """Load libptamd.so and bind every declared symbol.  Raises if the library is not built — there is
-    deliberately no fallback implementation."""
-    global _lib
+    """Load libptamd.so and bind every declared symbol.  Raises if the library is not built - there is
+    deliberately no fallback implementation - or if the process holds two HIP runtimes (see _settle_hip_runtime)."""
+    global _lib, _runtime_note
     if _lib is not None and path is None:
         return _lib
     p = path or os.environ.get("PTAMD_LIB", LIB_PATH)
     if not os.path.exists(p):
         raise PtamdError(f"{p} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()')")
+    note = _settle_hip_runtime()
     lib = C.CDLL(p)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the export is missing
         fn.restype = restype
         fn.argtypes = argtypes
+    ri = RuntimeInfo()
+    lib.pt_get_runtime_info(C.byref(ri))
+    if ri.hip_runtimes_mapped > 1 or ri.hsa_runtimes_mapped > 1:
+        raise PtamdError("two GPU runtimes are mapped into this process (" + ri.all_mapped.decode() + "): only the one that initialises "
+                         "first would see the GPU.  Import torch, or platinum_amd, before anything else that links /opt/rocm's libamdhip64")
     if path is None:
         _lib = lib
+        _runtime_note = note
     return lib
 
 

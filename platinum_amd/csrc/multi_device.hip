@@ -25,6 +25,7 @@
 #include <thread>
 
 #include "renderer_state.h"
+#include "runtime_identity.h"
 
 namespace {
 
@@ -84,13 +85,25 @@ struct Rccl {
   void* lib = nullptr;
   static constexpr ncclDataType_t kFloat32 = ncclFloat32;
   static constexpr ncclRedOp_t kSum = ncclSum;
+  std::string path;  // the shared object the entry points were bound from
+  // Prefers a librccl that is ALREADY mapped (in a process that holds PyTorch that is torch's bundled copy, built against the HIP runtime
+  // the process runs on): loading a second RCCL beside it would be a second set of collectives over the same runtime at best, and one
+  // linked against the other HIP runtime at worst.  Only when none is mapped is one searched for (this library's RUNPATH: /opt/rocm/lib).
+  // The resolved path is logged once and reported by pt_get_runtime_info.
   bool load(std::string* why) {
     if (lib && CommInitAll) return true;
-    if (!lib)
-      for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-        lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) {
+      const RuntimeObjects mapped = mapped_runtime_objects();
+      for (const std::string& p : mapped.rccl) {
+        lib = dlopen(p.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
         if (lib) break;
       }
+      if (!lib)
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
+          lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+          if (lib) break;
+        }
+    }
     if (!lib) { const char* e = dlerror(); *why = std::string("cannot load librccl.so: ") + (e ? e : "?"); return false; }
     bool ok = true;
     auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) { *why = std::string("librccl.so lacks ") + n; ok = false; } return p; };
@@ -100,8 +113,15 @@ struct Rccl {
     GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
     GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
     GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-    if (!ok) CommInitAll = nullptr;
-    return ok;
+    if (!ok) { CommInitAll = nullptr; return false; }
+    path = object_of((const void*)CommInitAll);
+    // RCCL brings its own DT_NEEDED libamdhip64: if that mapped a second HIP runtime, its collectives would run on a runtime that
+    // does not own this library's buffers and streams
+    const std::string conflict = runtime_conflict();
+    if (!conflict.empty()) { *why = "after loading " + path + ": " + conflict; CommInitAll = nullptr; return false; }
+    if (!getenv("PTAMD_QUIET"))
+      fprintf(stderr, "ptamd: RCCL bound from %s (HIP runtime %s)\n", path.c_str(), object_of((const void*)&hipRuntimeGetVersion).c_str());
+    return true;
   }
 };
 static_assert(ncclFloat32 == 7 && ncclSum == 0, "rccl.h enumerators this file was written against");
@@ -109,6 +129,11 @@ Rccl g_rccl;
 std::mutex g_rccl_mutex;
 
 }  // namespace
+
+std::string pt_rccl_bound_path() {
+  std::lock_guard<std::mutex> l(g_rccl_mutex);
+  return g_rccl.CommInitAll ? g_rccl.path : std::string();
+}
 
 // A physical device of the group: the members on it, the scratch image they are summed into, its RCCL rank.
 struct PhysDevice {

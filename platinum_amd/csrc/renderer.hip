@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "queue_plan.h"
+#include "runtime_identity.h"
 #include "renderer_state.h"
 
 using namespace pt;
@@ -176,10 +177,33 @@ extern "C" int pt_plan_queues(uint32_t width, uint32_t height, uint32_t spp, uin
   return rc == PT_OK ? PT_OK : fail(rc, std::string("pt_plan_queues: ") + why);
 }
 
+std::string pt_rccl_bound_path();  // multi_device.hip: "" until RCCL has been loaded
+
+extern "C" int pt_get_runtime_info(pt_runtime_info* out) {
+  if (!out) return fail(PT_ERR_INVALID_ARGUMENT, "pt_get_runtime_info: null argument");
+  memset(out, 0, sizeof(*out));
+  const RuntimeObjects o = mapped_runtime_objects();
+  auto put = [](char* dst, size_t cap, const std::string& s) { snprintf(dst, cap, "%s", s.c_str()); };
+  put(out->hip_runtime_path, sizeof(out->hip_runtime_path), object_of((const void*)&hipRuntimeGetVersion));
+  put(out->hsa_runtime_path, sizeof(out->hsa_runtime_path), o.hsa.empty() ? std::string() : o.hsa[0]);
+  put(out->rccl_path, sizeof(out->rccl_path), pt_rccl_bound_path());
+  out->hip_runtimes_mapped = (uint32_t)o.hip.size();
+  out->hsa_runtimes_mapped = (uint32_t)o.hsa.size();
+  out->rccl_mapped = (uint32_t)o.rccl.size();
+  int v = 0;
+  out->hip_runtime_version = hipRuntimeGetVersion(&v) == hipSuccess ? v : 0;
+  put(out->all_mapped, sizeof(out->all_mapped), join_paths(o.hip) + " | " + join_paths(o.hsa) + " | " + join_paths(o.rccl));
+  return PT_OK;
+}
+
 int dev_create(const pt_create_info* info, int device_ordinal, pt_renderer** out) {
   if (!info || !out) return fail(PT_ERR_INVALID_ARGUMENT, "pt_create: null argument");
   *out = nullptr;
   if (info->abi_version != PT_ABI_VERSION) return fail(PT_ERR_INVALID_ARGUMENT, "pt_create: ABI version mismatch");
+  {  // one HIP runtime over one HSA runtime per process, or whoever initialises second sees no GPU (runtime_identity.h)
+    const std::string conflict = runtime_conflict();
+    if (!conflict.empty()) return fail(PT_ERR_RUNTIME_CONFLICT, "pt_create: " + conflict);
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(PT_ERR_NO_DEVICE, "pt_create: no HIP device available (this library has no CPU fallback)");
@@ -233,7 +257,7 @@ void dev_destroy(pt_renderer* r) {
   (void)hipSetDevice(r->device);
   if (r->stream) (void)hipStreamSynchronize(r->stream);
   r->drop_timed();
-  r->free_scene();
+  r->release_all();  // the scene arrays, the queues AND the BVH builder's kept scratch (LbvhScratch has no destructor of its own)
   if (r->batch_done) (void)hipEventDestroy(r->batch_done);
   if (r->own_stream) (void)hipStreamDestroy(r->own_stream);
   delete r;
@@ -482,9 +506,15 @@ int flush_pending(pt_renderer* r, bool all) {
   while (r->launched < r->accumulated) {
     const uint64_t pending = r->accumulated - r->launched;
     bool idle = true;
-    if (r->batch_done_valid && hipEventQuery(r->batch_done) != hipSuccess) {
-      idle = false;
-      (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure: do not leave it for the next hipGetLastError() check
+    if (r->batch_done_valid) {
+      const hipError_t q = hipEventQuery(r->batch_done);
+      if (q == hipErrorNotReady) {
+        idle = false;
+        (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure: do not leave it for the next hipGetLastError() check
+      } else if (q != hipSuccess) {  // a fault or a lost context is NOT "still busy": report it now, not at some later wait
+        (void)hipGetLastError();
+        return fail(PT_ERR_HIP, std::string("pt_render_step: the previous batch failed: ") + hipGetErrorString(q));
+      }
     }
     if (!all && !idle && pending < r->samples_in_flight) break;
     const uint32_t ns = (uint32_t)std::min<uint64_t>(pending, r->samples_in_flight);

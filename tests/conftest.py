@@ -13,19 +13,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
-def pytest_collection_finish(session):
-    """GPU sessions: bring torch's HIP runtime up BEFORE libptamd.so initialises its own (the order bench.py uses: torch owns the
-    accumulator tensor, then the library is created).  torch's wheel bundles its own libamdhip64 / libhsa-runtime64; a torch that
-    first touches the GPU after the library has done so can fail with "No HIP GPUs are available" depending on what ran in between
-    (seen once when the test files were run in a non-alphabetical order)."""
-    if not any(item.get_closest_marker("gpu") for item in session.items):
-        return
-    try:
-        import torch
-        if torch.cuda.device_count() > 0:
-            torch.zeros(1, device="cuda:0")
-    except Exception:
-        pass
+# (r4) The former torch-first hook is gone.  It hid a load-order fault: torch's wheel bundles its own libamdhip64 / libhsa-runtime64,
+# and a libptamd.so loaded BEFORE torch mapped /opt/rocm's copies beside them - two HIP runtimes, the second of which never sees the
+# GPU ("No HIP GPUs are available").  platinum_amd.abi.load_library() now settles the process on ONE runtime in either order and
+# pt_create refuses a process that holds two (tests/test_runtime_identity.py).
+
+STRUCTURE_ENV = ("PTAMD_BVH4", "PTAMD_RADIX_TREE", "PTAMD_BVH_LEGACY", "PTAMD_TWO_LEVEL", "PTAMD_TEST_W6_LEVELS")
+
+
+def skip_if_structure_env_preset():
+    """Tests that switch the acceleration-structure variables themselves compare "default" against "forced": they mean nothing when the
+    whole session already runs with one of them exported (the sweeps of DESIGN section 2 do that), so they skip."""
+    preset = [v for v in STRUCTURE_ENV if v in os.environ]
+    if preset:
+        pytest.skip("preset for the whole session: " + ", ".join(preset))
 
 
 @pytest.fixture(scope="session")

@@ -13,6 +13,7 @@ from platinum_amd import abi, scenes
 from platinum_amd.renderer import make_params
 
 import oracle_lib
+from conftest import skip_if_structure_env_preset
 
 pytestmark = pytest.mark.gpu
 
@@ -539,6 +540,7 @@ def test_four_wide_fallback_form_gives_the_same_hits_and_radiance(gpu_renderer, 
     """r03: the device build emits 6-wide nodes (BvhNode6) by default — every other test in this file runs on them.  $PTAMD_BVH4 keeps the
     4-wide form (what the fallback builders — radix tree, per-pass launches, trees deeper than the stack at five pushes per level — and the
     two-level structure use); it must give the oracle's answers too, from a tree with more nodes."""
+    skip_if_structure_env_preset()
     cases = {"field": [scenes.field_scene(8)], "fuzz": [scenes.random_scene(s) for s in (3, 7, 11, 19)], "textured": [scenes.textured_scene()]}[which]
     for sc in cases:
         w, h, bounces = 128, 72, 6
@@ -561,6 +563,7 @@ def test_four_wide_fallback_form_gives_the_same_hits_and_radiance(gpu_renderer, 
 def test_six_wide_tree_deeper_than_the_stack_is_rebuilt_four_wide(gpu_renderer, monkeypatch):
     """A tree deeper than the traversal stack holds at five pushes per level must come back in the 4-wide form (three per level) from the
     same build call.  No test scene is that deep, so $PTAMD_TEST_W6_LEVELS lowers the 6-wide limit: the retry path runs for real."""
+    skip_if_structure_env_preset()
     sc = scenes.field_scene(8)
     w, h, bounces = 96, 54, 5
     gpu_renderer.selectKernel(abi.INTEGRATOR_MIS)
@@ -741,23 +744,21 @@ def test_render_scene_tool_end_to_end(tmp_path):
     assert data[:8] == b"\x89PNG\r\n\x1a\n" and len(data) > 1000 and "Msamples/s" in p.stdout
 
 
-def test_radix_tree_fallback_builder_gives_the_same_image(gpu_renderer):
+def test_radix_tree_fallback_builder_gives_the_same_image(gpu_renderer, monkeypatch):
     """The Karras radix tree (fallback of the PLOC builder, PTAMD_RADIX_TREE=1) and the PLOC tree answer every ray alike —
     the intersection contract does not depend on the acceleration structure."""
-    import os
+    skip_if_structure_env_preset()
     sc = scenes.field_scene(8)
     p = _start(gpu_renderer, sc, 160, 90, 2, 6)
     nodes_ploc = gpu_renderer.stats().bvh_nodes
     gpu_renderer.render(0)
     a = gpu_renderer.readbackAccumulator()
-    os.environ["PTAMD_RADIX_TREE"] = "1"
-    try:
-        _start(gpu_renderer, sc, 160, 90, 2, 6)
-        nodes_radix = gpu_renderer.stats().bvh_nodes
-        gpu_renderer.render(0)
-        b = gpu_renderer.readbackAccumulator()
-    finally:
-        del os.environ["PTAMD_RADIX_TREE"]
+    monkeypatch.setenv("PTAMD_RADIX_TREE", "1")
+    _start(gpu_renderer, sc, 160, 90, 2, 6)
+    nodes_radix = gpu_renderer.stats().bvh_nodes
+    gpu_renderer.render(0)
+    b = gpu_renderer.readbackAccumulator()
+    monkeypatch.delenv("PTAMD_RADIX_TREE")
     assert a.tobytes() == b.tobytes() and nodes_ploc != nodes_radix
     assert a.tobytes() == oracle_lib.OracleScene(sc, p).render(0, 2).tobytes()
 

@@ -67,6 +67,8 @@ def test_tall_strip_at_exactly_65536_slots_per_segment_matches_small_batches():
     last slot number is 0xffff.  The image must equal the same render traced 4 samples at a time (bit for bit: the running mean
     folds samples in index order whatever the batch size), and a request for 128 in flight must come back as 64."""
     import os
+    if "PTAMD_TILES_PER_SEG" in os.environ:
+        pytest.skip("$PTAMD_TILES_PER_SEG is preset for this session: the test sets and removes it itself")
     sc = scenes.cornell_scene("bench")
     w, h, spp, B = 8, 512, 64, 4
     os.environ["PTAMD_TILES_PER_SEG"] = "16"

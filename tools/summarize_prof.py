@@ -118,7 +118,7 @@ STREAM_IN_BYTES = {"k_shade": 68.0}
 
 lines = [f"# rocprofv3 summary — bench.py --workload {wl} (MI355X, {tag})", "",
          "Durations: `rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --no-cpu-baseline` (both of bench.py's passes)." % wl,
-         "Counters: separate `--pmc` passes of `bench.py --workload %s --pmc-pass --steps 2` (full 64-spp batches only)." % wl, "",
+         "Counters: separate `--pmc` passes of `bench.py --workload %s --pmc-pass --steps 2` (full batches of the library's own size only: 128 spp at 1080p)." % wl, "",
          "Calibration on known byte counts: " + json.dumps({k: (round(v, 4) if isinstance(v, float) and v < 100 else v) for k, v in calib.items()}), "",
          "| kernel | calls | total ms | avg ms | FETCH raw MiB/launch | FETCH corrected MiB/launch (x%.2f streams, x1 gathers, k_shade split: r02_calib_gather.md) | WRITE MiB/launch | HBM B/item (corr.) | VALU wave-insts/item | items |" % ff,
          "|---|---|---|---|---|---|---|---|---|---|"]

@@ -2,7 +2,8 @@
 """Host probes of tree shapes (tests/emu EMU_WIDE_PROBE): nodes / triangle tests per closest-hit ray for 4/6/8-wide trees and multi-triangle leaves.
     python tools/wide_probe.py c3 c2   (profiles/r03_tcp_bound.md section 4)"""
 import sys, os, ctypes as C
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+ROOT = os.environ.get('GRAFT_REPO_ROOT') or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 os.environ["EMU_WIDE_PROBE"]="1"; os.environ["EMU_MORTON"]="1"; os.environ["EMU_PLOC"]="8"; os.environ["EMU_SAH_COLLAPSE"]="1"
 import numpy as np, emu_lib
 from platinum_amd import scenes
