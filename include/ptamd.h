@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 3u
+#define PT_ABI_VERSION 4u /* 4: pt_get_runtime_info, PT_ERR_RUNTIME_CONFLICT, pt_stats::leaf_slots */
 
 /* ---------------------------------------------------------------------------------------------------------- */
 /* Enums (same numeric values as the reference)                                                                 */
@@ -55,7 +55,7 @@ typedef enum pt_error {
   PT_ERR_BAD_STATE = -5,     /* e.g. pt_render_step before pt_start_render */
   PT_ERR_UNSUPPORTED = -6,   /* a scene feature that is not implemented */
   PT_ERR_BAD_LUT = -7,
-  PT_ERR_RUNTIME_CONFLICT = -8 /* more than one HIP / HSA runtime mapped into the process (pt_get_runtime_info says which) */
+  PT_ERR_RUNTIME_CONFLICT = -8 /* more than one HIP runtime mapped into the process (pt_get_runtime_info says which) */
 } pt_error;
 
 /* ---------------------------------------------------------------------------------------------------------- */
@@ -235,7 +235,8 @@ int pt_create(const pt_create_info* info, pt_renderer** out);
 /* Which GPU runtime objects this process holds and which of them serves this library.  No counterpart in the reference (Metal is a
  * system framework); needed here because PyTorch's ROCm wheel bundles private copies of libamdhip64 / libhsa-runtime64 / librccl
  * that can end up mapped BESIDE the system's, and then only the runtime that initialises first sees the GPU.
- * pt_create returns PT_ERR_RUNTIME_CONFLICT when hip_runtimes_mapped or hsa_runtimes_mapped exceeds 1.  Touches no GPU. */
+ * pt_create returns PT_ERR_RUNTIME_CONFLICT when hip_runtimes_mapped exceeds 1 (a second libhsa-runtime64 under one HIP runtime is what
+ * rocprofv3's tool library maps: reported, not refused).  Touches no GPU. */
 typedef struct pt_runtime_info {
   char hip_runtime_path[512]; /* the libamdhip64 this library's hip* calls resolve to */
   char hsa_runtime_path[512]; /* the (first) libhsa-runtime64 mapped */
@@ -424,6 +425,8 @@ typedef struct pt_stats {
   double nodes_per_shadow_ray, tris_per_shadow_ray;
   uint32_t accel_two_level;    /* 1: the two-level structure is in use */
   uint32_t batches;            /* batches enqueued since pt_start_render (pt_render_step calls that arrive while the GPU is busy are merged) */
+  uint64_t leaf_slots;         /* 64-byte leaf slots of the acceleration structure: a slot holds one triangle, or two of one instance that share an
+                                  edge (one-BVH structure); tris_per_*_ray count triangle TESTS, a slot fetch serves one or two of them */
 } pt_stats;
 int pt_get_stats(pt_renderer* r, pt_stats* out);
 /* Enable per-kernel HIP-event timing (adds two event records per launch). */

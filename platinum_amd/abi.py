@@ -7,7 +7,7 @@ library is missing or cannot find a device, loading / pt_create raises.
 import ctypes as C
 import os
 
-PT_ABI_VERSION = 3
+PT_ABI_VERSION = 4
 
 # renderer_pt.hpp:21-26
 STATUS_BLOCKED, STATUS_READY, STATUS_BUSY, STATUS_DONE = 0, 1, 4, 8
@@ -181,7 +181,7 @@ class Stats(C.Structure):
         ("ms_accumulate", C.c_double), ("launches_closest", C.c_uint64), ("launches_shadow", C.c_uint64),
         ("nodes_per_closest_ray", C.c_double), ("tris_per_closest_ray", C.c_double),
         ("nodes_per_shadow_ray", C.c_double), ("tris_per_shadow_ray", C.c_double),
-        ("accel_two_level", C.c_uint32), ("batches", C.c_uint32),
+        ("accel_two_level", C.c_uint32), ("batches", C.c_uint32), ("leaf_slots", C.c_uint64),
     ]
 
 
@@ -340,7 +340,7 @@ def load_library(path=None):
         fn.argtypes = argtypes
     ri = RuntimeInfo()
     lib.pt_get_runtime_info(C.byref(ri))
-    if ri.hip_runtimes_mapped > 1 or ri.hsa_runtimes_mapped > 1:
+    if ri.hip_runtimes_mapped > 1:   # (two libhsa-runtime64 under ONE HIP runtime is what rocprofv3's tool library gives: legitimate)
         raise PtamdError("two GPU runtimes are mapped into this process (" + ri.all_mapped.decode() + "): only the one that initialises "
                          "first would see the GPU.  Import torch, or platinum_amd, before anything else that links /opt/rocm's libamdhip64")
     if path is None:

@@ -33,7 +33,48 @@ struct HostScene {
   pt_constants constants{};
   Mat3 idt{};
   uint32_t tri_count = 0;
+  // leaf slots of the one-BVH structure (pair_mesh_triangles): per unique mesh a list of primitives = one triangle or two consecutive
+  // triangles that share an edge; prim_tri[mesh_prim_base[m] + k] = first triangle of primitive k of mesh m (local index) | kPrimPairBit
+  std::vector<uint32_t> prim_tri, mesh_prim_base, inst_prim_base;
+  uint32_t prim_count = 0;  // primitives of the flattened scene = inst_prim_base.back()
 };
+constexpr uint32_t kPrimPairBit = 0x80000000u;
+
+// Groups the triangles of ONE mesh into leaf primitives: triangles t and t + 1 become one primitive when exactly two of t + 1's vertex
+// indices occur in t (a shared edge: the two halves of a quad, as every generator and exporter emits them), greedily from the front.
+// Same index = same object-space vertex = the same world-space point bit for bit after transformPoint, which is what lets the slot store
+// four corners for two triangles (pt_device.h TriRec).  `pairs` = false: one triangle per primitive.
+inline void pair_mesh_triangles(const uint32_t* idx, uint32_t tri_count, bool pairs, std::vector<uint32_t>* prim_tri) {
+  for (uint32_t t = 0; t < tri_count;) {
+    bool pair = false;
+    if (pairs && t + 1 < tri_count) {
+      const uint32_t* a = idx + 3 * (size_t)t;
+      const uint32_t* b = a + 3;
+      int shared = 0;
+      for (int k = 0; k < 3; k++) shared += (b[k] == a[0] || b[k] == a[1] || b[k] == a[2]) ? 1 : 0;
+      pair = shared == 2;
+    }
+    prim_tri->push_back(pair ? (t | kPrimPairBit) : t);
+    t += pair ? 2u : 1u;
+  }
+}
+inline void build_primitives(HostScene* hs, bool pairs) {
+  hs->prim_tri.clear();
+  hs->mesh_prim_base.assign(hs->meshes.size() + 1, 0u);
+  for (size_t m = 0; m < hs->meshes.size(); m++) {
+    hs->mesh_prim_base[m] = (uint32_t)hs->prim_tri.size();
+    pair_mesh_triangles(hs->indices.data() + 3 * (size_t)hs->meshes[m].tri_base, hs->meshes[m].tri_count, pairs, &hs->prim_tri);
+  }
+  hs->mesh_prim_base[hs->meshes.size()] = (uint32_t)hs->prim_tri.size();
+  hs->inst_prim_base.assign(hs->instances.size() + 1, 0u);
+  uint32_t total = 0;
+  for (size_t i = 0; i < hs->instances.size(); i++) {
+    hs->inst_prim_base[i] = total;
+    total += hs->mesh_prim_base[hs->instances[i].mesh + 1] - hs->mesh_prim_base[hs->instances[i].mesh];
+  }
+  hs->inst_prim_base[hs->instances.size()] = total;
+  hs->prim_count = total;
+}
 
 inline int hs_fail(std::string* err, int code, const char* msg) {
   if (err) *err = msg;

@@ -64,7 +64,8 @@ void launch_hit_records(hipStream_t s, uint32_t grid, const DeviceScene& S, Path
 // ---- LBVH (lbvh.hip) ----
 struct LbvhResult {
   BvhNode* nodes = nullptr;   // node_count records, the root first
-  TriRec* tris = nullptr;     // tri_count records: in leaf (Morton) order (one BVH), in flattening order (two-level)
+  TriRec* tris = nullptr;     // slot_count leaf slots: in leaf order (one BVH: one or two triangles each), in flattening order (two-level: one each)
+  uint32_t slot_count = 0;
   MeshTrav* mesh_trav = nullptr;  // two-level only: one record per mesh
   uint32_t root_ref = kInvalidRef;
   uint32_t node_count = 0;    // 4-wide nodes emitted
@@ -80,9 +81,12 @@ struct LbvhScratch {
   hipError_t ensure(size_t bytes);
   void release();
 };
+// How the flattened triangles are grouped into leaf slots (host_scene.h build_primitives; device copies).  prim_tri == nullptr: one triangle
+// per slot, slot = flattened triangle index.
+struct PrimTables { const uint32_t* prim_tri = nullptr; const uint32_t* mesh_prim_base = nullptr; const uint32_t* inst_prim_base = nullptr; uint32_t slot_count = 0; };
 // Flattens the instanced scene to world-space triangles and builds the BVH entirely on the device.
 // `S` needs positions / indices / meshes / instances filled in. Returns hipSuccess or the failing HIP error.
-hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_count, uint32_t tri_count, uint32_t stack_capacity,
+hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, const PrimTables& prims, uint32_t instance_count, uint32_t stack_capacity,
                       LbvhScratch* scratch, LbvhResult* out);
 // The two-level structure: a TLAS over the instances' world boxes + one object-space BLAS per mesh, in one node array
 // (depth4 = TLAS levels + deepest BLAS levels; the traversal stack also holds one exit marker).  `meshes` is the host copy

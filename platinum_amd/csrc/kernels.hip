@@ -334,7 +334,7 @@ __device__ __forceinline__ const BvhNode* stage_nodes(const DeviceScene& S, BvhN
 
 // ---- closest hit ---------------------------------------------------------------------------------------------------
 template <bool COUNT, bool TWO, bool W6 = false>
-__global__ void __launch_bounds__(TWO ? kTraceBlock2 : kBlock, TWO ? PT_TWO_BLOCKS_PER_CU : PT_TRACE_WAVES)
+__global__ void __launch_bounds__(TWO ? kTraceBlock2 : kBlock, TWO ? PT_TWO_BLOCKS_PER_CU : PT_CLOSEST_WAVES)
 k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments seg, uint32_t cur, BatchCounters* __restrict__ ctr, uint32_t bounce,
                 uint32_t* __restrict__ spill, int32_t* __restrict__ hitlog, uint32_t log_stride) {
   constexpr uint32_t kTB = TWO ? kTraceBlock2 : kBlock;
@@ -364,8 +364,8 @@ k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments se
       // (the hit log is only kept for one-sample batches)
       const uint32_t pixel = pixel_of_pid_1spp(segment_lbuf_base(seg, slot_segment(seg.nseg, ray)) + (f2u(st.rayD[ray].w) >> kMetaPidShift), S.width);
       int32_t* hl = &hitlog[((size_t)bounce * log_stride + pixel) * 2];
-      hl[0] = h.tri != kInvalidRef ? (int32_t)S.tris[h.tri].inst : -1;
-      hl[1] = h.tri != kInvalidRef ? (int32_t)S.tris[h.tri].prim : -1;
+      hl[0] = hl[1] = -1;
+      if (h.tri != kInvalidRef) triangle_ids(S, h.tri, &hl[0], &hl[1]);
     }
     ray = kInvalidRef;
   };
@@ -643,7 +643,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
 
 // ---- shadow (any hit) --------------------------------------------------------------------------------------------------
 template <bool COUNT, bool TWO, bool W6 = false>
-__global__ void __launch_bounds__(TWO ? kTraceBlock2 : kBlock, TWO ? PT_TWO_BLOCKS_PER_CU : PT_TRACE_WAVES)
+__global__ void __launch_bounds__(TWO ? kTraceBlock2 : kBlock, TWO ? PT_TWO_BLOCKS_PER_CU : PT_SHADOW_WAVES)
 k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments seg, BatchCounters* __restrict__ ctr, uint32_t bounce,
                uint32_t* __restrict__ spill) {
   constexpr uint32_t kTB = TWO ? kTraceBlock2 : kBlock;
@@ -852,11 +852,15 @@ __global__ void __launch_bounds__(kBlock) k_light_records(DeviceScene S, LightRe
   if (i < S.lightCount) { out[i] = make_light_rec(S, S.lights[i]); cdf[i] = S.lights[i].cumulativePower; }
 }
 
-// one ShadeRec per flattened triangle, in tris[] order (once per render, after the BVH build)
+// one ShadeRec per triangle of every leaf slot: entry 2 * slot + half (once per render, after the BVH build)
 __global__ void __launch_bounds__(kBlock) k_shade_records(DeviceScene S, ShadeRec* __restrict__ out) {
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= S.tri_count) return;
-  out[t] = make_shade_rec(S, S.tris[t]);
+  if (t >= 2u * S.slot_count) return;
+  const TriRec& tr = S.tris[t >> 1];
+  const uint32_t gid = (t & 1u) ? tr.gid_b : tr.gid_a;
+  if (gid == kInvalidRef) { out[t] = ShadeRec{}; return; }  // the B entry of a one-triangle slot: never referred to
+  const uint32_t inst = tr.inst_code & kSlotInstMask;
+  out[t] = make_shade_rec(S, inst, (gid >> 2) - S.instances[inst].tri_global_base);
 }
 
 // primary-ray records for pt_trace_primary: segment order -> pixel order
@@ -872,8 +876,7 @@ __global__ void __launch_bounds__(kBlock) k_hit_records(DeviceScene S, PathState
       pt_hit_record r;
       if (tri != kInvalidRef) {
         r.t = h.x; r.u = h.y; r.v = h.z;
-        r.instance = (int32_t)S.tris[tri].inst;
-        r.primitive = (int32_t)S.tris[tri].prim;
+        triangle_ids(S, tri, &r.instance, &r.primitive);
       } else {
         r.t = 0.0f; r.u = 0.0f; r.v = 0.0f; r.instance = -1; r.primitive = -1;
       }
@@ -960,7 +963,7 @@ void launch_fold_counters(hipStream_t s, const BatchCounters* ctr, Totals* tot, 
   hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(kBlock), 0, s, ctr, tot, seg, counted ? 1u : 0u);
 }
 void launch_shade_records(hipStream_t s, const DeviceScene& S, ShadeRec* out) {
-  if (S.tri_count) hipLaunchKernelGGL(k_shade_records, dim3((S.tri_count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, S, out);
+  if (S.slot_count) hipLaunchKernelGGL(k_shade_records, dim3((2u * S.slot_count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, S, out);
 }
 void launch_light_records(hipStream_t s, const DeviceScene& S, LightRec* out, float* cdf) {
   if (S.lightCount) hipLaunchKernelGGL(k_light_records, dim3((S.lightCount + kBlock - 1) / kBlock), dim3(kBlock), 0, s, S, out, cdf);

@@ -31,36 +31,57 @@ __device__ __forceinline__ int float_to_ordered(float f) {
 }
 __device__ __forceinline__ float ordered_to_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
-__global__ void __launch_bounds__(256) k_flatten(DeviceScene S, uint32_t instance_count, uint32_t tri_count,
-                                                  TriRec* __restrict__ tris, Box* __restrict__ boxes) {
+// One thread per leaf slot: the slot's one or two triangles in world space (fp32 transformPoint of the mesh vertices: the intersection
+// contract) and the slot's box.  P.prim_tri == nullptr: one triangle per slot, slot = flattened triangle index (two-level structure).
+__global__ void __launch_bounds__(256) k_flatten(DeviceScene S, PrimTables P, uint32_t instance_count, TriRec* __restrict__ tris, Box* __restrict__ boxes) {
   const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= tri_count) return;
-  // instance = last i with tri_global_base <= g
+  if (g >= P.slot_count) return;
+  // instance = last i whose first slot is <= g
   uint32_t lo = 0, hi = instance_count;
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
-    if (S.instances[mid].tri_global_base <= g) lo = mid; else hi = mid;
+    if ((P.prim_tri ? P.inst_prim_base[mid] : S.instances[mid].tri_global_base) <= g) lo = mid; else hi = mid;
   }
   const InstanceInfo inst = S.instances[lo];
   const MeshInfo mesh = S.meshes[inst.mesh];
-  const uint32_t prim = g - inst.tri_global_base;
+  uint32_t prim = g - inst.tri_global_base;
+  bool pair = false;
+  if (P.prim_tri) {
+    const uint32_t e = P.prim_tri[P.mesh_prim_base[inst.mesh] + (g - P.inst_prim_base[lo])];
+    prim = e & 0x7fffffffu;
+    pair = (e >> 31) != 0;
+  }
   const uint32_t* idx = &S.indices[3 * (size_t)(mesh.tri_base + prim)];
   const Xform X = load_xform(inst);
   const vec3 v0 = transformPoint(ld3(S.positions[mesh.vertex_base + idx[0]]), X);
   const vec3 v1 = transformPoint(ld3(S.positions[mesh.vertex_base + idx[1]]), X);
   const vec3 v2 = transformPoint(ld3(S.positions[mesh.vertex_base + idx[2]]), X);
-  const vec3 e1 = v1 - v0, e2 = v2 - v0;
+  vec3 v3_ = v0;
   TriRec t;
-  t.v0[0] = v0.x; t.v0[1] = v0.y; t.v0[2] = v0.z;
-  t.e1[0] = e1.x; t.e1[1] = e1.y; t.e1[2] = e1.z;
-  t.e2[0] = e2.x; t.e2[1] = e2.y; t.e2[2] = e2.z;
-  t.inst = lo; t.prim = prim;
-  t.gid = (g << 2) | material_class(S.materials[inst.material_base + S.slots[mesh.tri_base + prim]]);
+  uint32_t code = 0u;
+  t._pad = 0u;
+  t.gid_a = ((inst.tri_global_base + prim) << 2) | material_class(S.materials[inst.material_base + S.slots[mesh.tri_base + prim]]);
+  t.gid_b = kInvalidRef;
+  if (pair) {  // triangle prim + 1 shares two vertex indices with this one (pair_mesh_triangles): its corners by index comparison
+    for (int k = 0; k < 3; k++) {
+      const uint32_t ib = idx[3 + k];
+      uint32_t c = 3u;
+      if (ib == idx[0]) c = 0u; else if (ib == idx[1]) c = 1u; else if (ib == idx[2]) c = 2u;
+      else v3_ = transformPoint(ld3(S.positions[mesh.vertex_base + ib]), X);
+      code |= c << (2 * k);
+    }
+    t.gid_b = ((inst.tri_global_base + prim + 1u) << 2) | material_class(S.materials[inst.material_base + S.slots[mesh.tri_base + prim + 1u]]);
+  }
+  t.inst_code = lo | (code << kSlotInstBits);
+  t.q0[0] = v0.x; t.q0[1] = v0.y; t.q0[2] = v0.z;
+  t.q1[0] = v1.x; t.q1[1] = v1.y; t.q1[2] = v1.z;
+  t.q2[0] = v2.x; t.q2[1] = v2.y; t.q2[2] = v2.z;
+  t.q3[0] = v3_.x; t.q3[1] = v3_.y; t.q3[2] = v3_.z;
   tris[g] = t;
   Box b;
-  b.lo[0] = fminf(v0.x, fminf(v1.x, v2.x)); b.hi[0] = fmaxf(v0.x, fmaxf(v1.x, v2.x));
-  b.lo[1] = fminf(v0.y, fminf(v1.y, v2.y)); b.hi[1] = fmaxf(v0.y, fmaxf(v1.y, v2.y));
-  b.lo[2] = fminf(v0.z, fminf(v1.z, v2.z)); b.hi[2] = fmaxf(v0.z, fmaxf(v1.z, v2.z));
+  b.lo[0] = fminf(fminf(v0.x, v3_.x), fminf(v1.x, v2.x)); b.hi[0] = fmaxf(fmaxf(v0.x, v3_.x), fmaxf(v1.x, v2.x));
+  b.lo[1] = fminf(fminf(v0.y, v3_.y), fminf(v1.y, v2.y)); b.hi[1] = fmaxf(fmaxf(v0.y, v3_.y), fmaxf(v1.y, v2.y));
+  b.lo[2] = fminf(fminf(v0.z, v3_.z), fminf(v1.z, v2.z)); b.hi[2] = fmaxf(fmaxf(v0.z, v3_.z), fmaxf(v1.z, v2.z));
   b._pad[0] = b._pad[1] = 0.0f;
   boxes[g] = b;
 }
@@ -1087,12 +1108,12 @@ void LbvhScratch::release() {
 }
 
 // Flattens the instanced scene to world-space triangles and builds ONE BVH over them (the default: fewest node visits per ray).
-hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_count, uint32_t tri_count, uint32_t stack_capacity,
+hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, const PrimTables& prims, uint32_t instance_count, uint32_t stack_capacity,
                       LbvhScratch* scratch, LbvhResult* out) {
   *out = LbvhResult{};
-  if (tri_count == 0) return hipSuccess;
+  if (prims.slot_count == 0) return hipSuccess;
   hipError_t err = hipSuccess;
-  const uint32_t n = tri_count;
+  const uint32_t n = prims.slot_count;  // the builder's primitives are the leaf slots (one triangle, or two that share an edge)
   const uint32_t blocks = (n + 255) / 256;
   TriRec* tris_tmp = nullptr; Box* leaf_boxes = nullptr; BvhNode* nodes_tmp = nullptr; uint32_t *order = nullptr, *tri_perm = nullptr;
   TreeInfo info;
@@ -1113,7 +1134,7 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
   nodes_tmp = tmp.take<BvhNode>(n > 1 ? n - 1 : 1);
   tree_scratch = tmp.take<char>(tree_bytes);
   LB_CHECK(hipMalloc(&out->tris, sizeof(TriRec) * (size_t)n));
-  hipLaunchKernelGGL(k_flatten, dim3(blocks), dim3(256), 0, s, S, instance_count, n, tris_tmp, leaf_boxes);
+  hipLaunchKernelGGL(k_flatten, dim3(blocks), dim3(256), 0, s, S, prims, instance_count, tris_tmp, leaf_boxes);
   LB_CHECK(build_tree(s, n, leaf_boxes, stack_capacity, use_ploc, nodes_tmp, 0u, kLeafBit, false, order, tri_perm, tree_scratch, tree_bytes, &info));
   if (info.wide6) hipLaunchKernelGGL(k_reorder_tris6, dim3(blocks), dim3(256), 0, s, (int)n, tri_perm, order, tris_tmp, out->tris);  // triangles in the collapse's leaf numbering
   else hipLaunchKernelGGL(k_reorder_tris, dim3(blocks), dim3(256), 0, s, (int)n, order, tris_tmp, out->tris);  // triangles in leaf (Morton) order
@@ -1127,6 +1148,7 @@ hipError_t build_lbvh(hipStream_t s, const DeviceScene& S, uint32_t instance_cou
   out->node_count = info.node_span;
   out->depth4 = info.depth4;
   out->wide6 = info.wide6;
+  out->slot_count = n;
 
 done:
   if (err != hipSuccess) {
@@ -1230,7 +1252,11 @@ hipError_t build_two_level(hipStream_t s, const DeviceScene& S, const MeshInfo* 
   LB_CHECK(hipMalloc(&out->mesh_trav, sizeof(MeshTrav) * (size_t)mesh_count));
   LB_CHECK(hipMemsetAsync(out->mesh_trav, 0, sizeof(MeshTrav) * (size_t)mesh_count, s));
   // world-space triangles in flattening order (the intersection contract's triangles) and the instances' world boxes
-  hipLaunchKernelGGL(k_flatten, dim3((tri_count + 255) / 256), dim3(256), 0, s, S, instance_count, tri_count, out->tris, tri_boxes);
+  {
+    PrimTables singles;  // one triangle per slot, in flattening order: a BLAS leaf `primitive` of instance i is slot tri_global_base(i) + primitive
+    singles.slot_count = tri_count;
+    hipLaunchKernelGGL(k_flatten, dim3((tri_count + 255) / 256), dim3(256), 0, s, S, singles, instance_count, out->tris, tri_boxes);
+  }
   hipLaunchKernelGGL(k_instance_boxes, dim3(instance_count), dim3(256), 0, s, S, tri_boxes, inst_boxes);
   LB_CHECK(build_tree(s, instance_count, inst_boxes, stack_capacity, use_ploc, nodes_tmp, 0u, kInstBit, true, nullptr, nullptr, tree_scratch, tree_bytes, &tlas));
   base = tlas.node_span;
@@ -1256,6 +1282,7 @@ hipError_t build_two_level(hipStream_t s, const DeviceScene& S, const MeshInfo* 
   out->root_ref = tlas.root_ref;
   out->node_count = base;
   out->depth4 = tlas.depth4 + deepest_blas;
+  out->slot_count = tri_count;
 
 done:
   if (err != hipSuccess) {

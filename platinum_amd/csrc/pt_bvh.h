@@ -15,21 +15,19 @@ namespace pt {
 
 struct RayHit {
   float t, u, v;
-  uint32_t tri;  // index into DeviceScene::tris (leaf order); kInvalidRef = miss
+  uint32_t tri;  // 2 * (index into DeviceScene::tris, leaf order) + half; kInvalidRef = miss
   uint32_t gid;
 };
 
 // Moeller-Trumbore with a fixed operation order.  Returns true and (t,u,v) when det != 0, 0 <= u <= 1, 0 <= v,
-// u + v <= 1 and tmin <= t <= tmax.
-PT_HD bool intersect_triangle(vec3 o, vec3 d, float tmin, float tmax, const TriRec& tr, float* t_out, float* u_out,
+// u + v <= 1 and tmin <= t <= tmax.  (v0, e1 = v1 - v0, e2 = v2 - v0: world-space, the caller forms the edges.)
+PT_HD bool intersect_triangle(vec3 o, vec3 d, float tmin, float tmax, vec3 v0, vec3 e1, vec3 e2, float* t_out, float* u_out,
                               float* v_out) {
-  const vec3 e1 = v3(tr.e1[0], tr.e1[1], tr.e1[2]);
-  const vec3 e2 = v3(tr.e2[0], tr.e2[1], tr.e2[2]);
   const vec3 p = cross(d, e2);
   const float det = dot(e1, p);
   if (det == 0.0f) return false;
   const float inv = 1.0f / det;
-  const vec3 s = o - v3(tr.v0[0], tr.v0[1], tr.v0[2]);
+  const vec3 s = o - v0;
   const float u = dot(s, p) * inv;
   if (!(u >= 0.0f && u <= 1.0f)) return false;
   const vec3 q = cross(s, e1);
@@ -41,6 +39,25 @@ PT_HD bool intersect_triangle(vec3 o, vec3 d, float tmin, float tmax, const TriR
   *u_out = u;
   *v_out = v;
   return true;
+}
+
+// corner c (0..3) of a leaf slot: quarter c of the record
+PT_HD vec3 slot_corner(const TriRec* rec, uint32_t c) {
+  const float* p = reinterpret_cast<const float*>(rec) + 4u * c;
+#if defined(__HIP_DEVICE_COMPILE__)
+  struct f3 { float x, y, z; };
+  const f3 v = ldg(reinterpret_cast<const f3*>(p));
+  return v3(v.x, v.y, v.z);
+#else
+  return v3(p[0], p[1], p[2]);
+#endif
+}
+// (instance, primitive) of triangle `tri` = 2 * slot + half: what the hit log and pt_trace_primary report
+PT_HD void triangle_ids(const DeviceScene& S, uint32_t tri, int32_t* inst, int32_t* prim) {
+  const TriRec& tr = S.tris[tri >> 1];
+  const uint32_t gid = (tri & 1u) ? tr.gid_b : tr.gid_a, in = tr.inst_code & kSlotInstMask;
+  *inst = (int32_t)in;
+  *prim = (int32_t)((gid >> 2) - S.instances[in].tri_global_base);
 }
 
 // Conservative slab test: entry distance or -1 if missed. fmin/fmax drop the NaN of 0 * inf.
@@ -65,6 +82,15 @@ PT_HD float slab_entry(const float lo[3], const float hi[3], vec3 o, vec3 inv, f
 // on C3 10 % faster, C2 unchanged; 8 waves (64 VGPRs, 12 + 6 rows) spills registers and is slower.
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 7
+#endif
+// r4: with two triangles per leaf slot the closest-hit kernel wants 78 registers; at 7 waves per SIMD (72) it spills 5 of them, at 6 none —
+// measured per 128-spp step, C3 / C2: closest 112.5 / 36.8 ms at 7 blocks per CU, 109.3 / 35.3 at 6; shadow (71 registers, no spills) 50.8 /
+// 21.4 at 7, 52.2 / 21.5 at 6.  So each kernel gets its own occupancy.
+#ifndef PT_CLOSEST_WAVES
+#define PT_CLOSEST_WAVES 6
+#endif
+#ifndef PT_SHADOW_WAVES
+#define PT_SHADOW_WAVES PT_TRACE_WAVES
 #endif
 #ifndef PT_LDS_STACK
 #define PT_LDS_STACK 13
@@ -114,7 +140,7 @@ struct TraversalStack {
   }
 };
 
-struct TraversalCount { uint32_t nodes = 0, tris = 0; };
+struct TraversalCount { uint32_t nodes = 0, tris = 0, leaves = 0; };  // node visits, triangle tests, leaf-slot fetches (one or two tests each)
 
 // Resumable traversal: one ray's state lives in registers (+ its LDS/HBM stack and leaf queue) and advances one node
 // per trav_node() / one triangle per trav_pending_leaf(), so a persistent kernel can hand a finished lane a new ray
@@ -153,21 +179,45 @@ PT_HD bool alpha_test(const DeviceScene& S, uint32_t instanceIdx, uint32_t prim,
   return alpha > r;
 }
 
-PT_HD void trav_leaf(const DeviceScene& S, TravState& ts, uint32_t ref, bool any, bool* finished, TraversalCount* cnt) {
-  const uint32_t ti = ref & ~kLeafBit;
-  const TriRec tr = S.tris[ti];
-  if (cnt) cnt->tris++;
+// One candidate triangle against the ray's current best: the closest-hit rule (min t, ties to the lowest global id) or accept-any.
+PT_HD bool trav_test(const DeviceScene& S, TravState& ts, vec3 v0, vec3 v1, vec3 v2, uint32_t gid, uint32_t inst, bool cutouts, uint32_t tri, bool any) {
   float t, u, v;
-  if (!intersect_triangle(ts.o, ts.d, ts.tmin, ts.best.t, tr, &t, &u, &v)) return;
-  if (S.has_alpha && (S.instances[tr.inst].flags & kInstanceNonOpaque) && !alpha_test(S, tr.inst, tr.prim, u, v, ts.payload)) return;
-  if (any) {
-    ts.best.tri = ti;
-    *finished = true;
-    return;
-  }
+  if (!intersect_triangle(ts.o, ts.d, ts.tmin, ts.best.t, v0, v1 - v0, v2 - v0, &t, &u, &v)) return false;
+  if (cutouts && !alpha_test(S, inst, (gid >> 2) - S.instances[inst].tri_global_base, u, v, ts.payload)) return false;
+  if (any) { ts.best.tri = tri; return true; }
   // intersect_triangle admitted t <= best.t; equal t needs the id tie-break
-  if (t < ts.best.t || ts.best.tri == kInvalidRef || tr.gid < ts.best.gid) {
-    ts.best.t = t; ts.best.u = u; ts.best.v = v; ts.best.tri = ti; ts.best.gid = tr.gid;
+  if (t < ts.best.t || ts.best.tri == kInvalidRef || gid < ts.best.gid) {
+    ts.best.t = t; ts.best.u = u; ts.best.v = v; ts.best.tri = tri; ts.best.gid = gid;
+  }
+  return false;
+}
+
+// One leaf slot: triangle A, then triangle B when the slot holds a pair.  The order of the two tests does not matter (min t, ties to the
+// lowest global id — the same rule that makes the answer independent of the tree).  B's corners are loaded after A's test (TriRec).
+PT_HD void trav_leaf(const DeviceScene& S, TravState& ts, uint32_t ref, bool any, bool* finished, TraversalCount* cnt) {
+  const uint32_t slot = ref & ~kLeafBit;
+  const TriRec* rec = &S.tris[slot];
+  uint32_t gid_b, inst_code;
+  {
+    const TriRec& tr = *rec;
+    const vec3 v0 = v3(tr.q0[0], tr.q0[1], tr.q0[2]), v1 = v3(tr.q1[0], tr.q1[1], tr.q1[2]), v2 = v3(tr.q2[0], tr.q2[1], tr.q2[2]);
+    const uint32_t gid_a = tr.gid_a;
+    gid_b = tr.gid_b; inst_code = tr.inst_code;
+    if (cnt) { cnt->leaves++; cnt->tris++; }
+    const uint32_t inst = inst_code & kSlotInstMask;
+    const bool cutouts = S.has_alpha && (S.instances[inst].flags & kInstanceNonOpaque);
+    if (trav_test(S, ts, v0, v1, v2, gid_a, inst, cutouts, 2u * slot, any)) { *finished = true; return; }
+  }
+  if (gid_b == kInvalidRef) return;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_PAIR_HOIST)
+  asm volatile("" : "+v"(gid_b), "+v"(inst_code) : "v"(ts.best.t));  // keep B's loads behind A's test (hoisted, they cost A's registers)
+#endif
+  {
+    const vec3 v0 = slot_corner(rec, (inst_code >> 26) & 3u), v1 = slot_corner(rec, (inst_code >> 28) & 3u), v2 = slot_corner(rec, inst_code >> 30);
+    if (cnt) cnt->tris++;
+    const uint32_t inst = inst_code & kSlotInstMask;
+    const bool cutouts = S.has_alpha && (S.instances[inst].flags & kInstanceNonOpaque);
+    if (trav_test(S, ts, v0, v1, v2, gid_b, inst, cutouts, 2u * slot + 1u, any)) *finished = true;
   }
 }
 

@@ -29,19 +29,28 @@ constexpr uint32_t kInstanceNonOpaque = 1u;
 static_assert(sizeof(InstanceInfo) == 64, "InstanceInfo");
 
 // ---- BVH -------------------------------------------------------------------------------------------------------
-// World-space triangle record in BVH leaf order: 48 B of payload (3 x dwordx4) in a 64-byte-aligned slot, so that a
-// triangle test is ONE 64-byte L2 request (48-byte records straddle a sector boundary every other time; the C3 closest-hit
-// kernel runs at ~90 % of the L2's random-request rate, tools/calib_gather.hip, so requests are what count).
+// Leaf slot of the BVH: ONE world-space triangle, or (r4) TWO triangles of one instance that share an edge (every quad of a lat / long
+// sphere, every wall: consecutive triangles of a mesh with two vertex indices in common — host_scene.h pair_mesh_triangles).  64 bytes,
+// 64-byte aligned: a leaf test is ONE 64-byte L2 request whether it tests one triangle or two.  The slot holds the four world-space
+// corners (fp32 transformPoint of the mesh vertices, the intersection contract); the edges e1 = v1 - v0, e2 = v2 - v0 that Moeller-Trumbore
+// consumes are formed in registers with the very subtraction k_flatten used to store, so the test sees the same fp32 operands as before and
+// the contract (min t, ties to the lowest global id) is untouched.  Triangle A = (q0, q1, q2) in ITS vertex order; triangle B's corners
+// are three of q0..q3 in B's own order, named by `code`.  r3 kept one triangle per slot (v0, e1, e2): 66 MB of slots on C3, now 34 MB,
+// and the bottom level of the tree went with them.
+// Layout: four 16-byte quarters, one corner each, a word of metadata in the fourth lane of the first three.  Triangle A needs quarters
+// 0..2 (three dwordx4 loads: what r3's one-triangle record cost); triangle B's corners are fetched AFTER A's test, one 12-byte load per
+// corner at quarter `code`, from the line A's loads have just brought into L1 — holding all four corners in registers across A's test cost
+// the 72-VGPR trace kernels 11 more spilled registers and 37 % of their speed (measured, r4).
 struct alignas(64) TriRec {
-  float v0[3];
-  float e1[3];
-  float e2[3];
-  uint32_t inst;   // instance id
-  uint32_t prim;   // primitive id inside the instance's mesh
-  uint32_t gid;    // (global id << 2) | material class; global id = InstanceInfo.tri_global_base + prim is the closest-hit
-                   // tie-break key (the class bits sit below it, so comparing this field orders by global id)
+  float q0[3]; uint32_t gid_a;      // (global id << 2) | material class; global id = InstanceInfo.tri_global_base + prim is the closest-hit
+                                    // tie-break key (the class bits sit below it, so comparing this field orders by global id)
+  float q1[3]; uint32_t gid_b;      // the same for triangle B; kInvalidRef: the slot holds one triangle
+  float q2[3]; uint32_t inst_code;  // instance id (both triangles) in bits [25:0]; bits [27:26], [29:28], [31:30]: which quarter holds B's v0, v1, v2
+  float q3[3]; uint32_t _pad;
 };
 static_assert(sizeof(TriRec) == 64, "TriRec");
+constexpr uint32_t kSlotInstBits = 26, kSlotInstMask = (1u << kSlotInstBits) - 1u;  // < 2^26 instances (checked at pt_start_render)
+// A triangle is named by 2 * slot + half (half 1 = triangle B) wherever one is referred to: RayHit::tri, the hit record, shade_recs[].
 // Hit record word 3: triangle index (28 bits) | material class << 28; kInvalidRef = miss.  The class (which BSDF lobes the
 // material can take: see material_class) lets k_shade put hits of one kind into one wave.
 constexpr uint32_t kHitTriMask = 0x0fffffffu;
@@ -186,10 +195,11 @@ struct DeviceScene {
   const pt_area_light* lights;
   const BvhNode* nodes;
   const TriRec* tris;
-  const ShadeRec* shade_recs;  // tri_count records, same order as tris[]
+  const ShadeRec* shade_recs;  // 2 * slot_count records: entry 2 * slot + half (the B entry of a one-triangle slot is unused)
   const LightRec* light_recs;  // lightCount records, same order as lights[]
   const float* light_cdf;      // lightCount values: AreaLight::cumulativePower on its own (what sampleLightPower's binary search reads)
-  uint32_t tri_count;
+  uint32_t tri_count;      // flattened triangles
+  uint32_t slot_count;     // leaf slots in tris[] (<= tri_count: a slot holds one or two triangles)
   uint32_t root_ref;       // kLeafBit|0 for a single-triangle scene, the root's node index otherwise, kInvalidRef when empty
   const InstanceTrav* inst_trav;  // two-level structure only (two_level != 0): root_ref is the TLAS root, tris[] is in flattening order
   const MeshTrav* mesh_trav;

@@ -53,14 +53,14 @@ PT_HD uint32_t material_class(const pt_material_gpu& m) {
 
 // getIntersectionData's table walk (kernel.metal:118-141) and its geometric normal (:150-162), done once per flattened
 // triangle instead of once per hit
-PT_HD ShadeRec make_shade_rec(const DeviceScene& S, const TriRec& tr) {
-  const InstanceInfo& inst = S.instances[tr.inst];
+PT_HD ShadeRec make_shade_rec(const DeviceScene& S, uint32_t instanceIdx, uint32_t prim) {
+  const InstanceInfo& inst = S.instances[instanceIdx];
   const MeshInfo mesh = S.meshes[inst.mesh];
-  const uint32_t* __restrict__ idx = &S.indices[3 * (size_t)(mesh.tri_base + tr.prim)];
+  const uint32_t* __restrict__ idx = &S.indices[3 * (size_t)(mesh.tri_base + prim)];
   ShadeRec r;
   r.v[0] = mesh.vertex_base + idx[0]; r.v[1] = mesh.vertex_base + idx[1]; r.v[2] = mesh.vertex_base + idx[2];
-  r.material = inst.material_base + S.slots[mesh.tri_base + tr.prim];
-  r.inst = tr.inst;
+  r.material = inst.material_base + S.slots[mesh.tri_base + prim];
+  r.inst = instanceIdx;
   const vec3 p0 = ld3(S.positions[r.v[0]]), p1 = ld3(S.positions[r.v[1]]), p2 = ld3(S.positions[r.v[2]]);
   const vec3 geometricNormal = normalize(cross(p1 - p0, p2 - p0));
   const vec3 ws = normalize(transformVec(geometricNormal, load_xform(inst)));
@@ -132,7 +132,7 @@ struct ShadeIn {
   uint32_t offset, dim;
   uint32_t bounce;
   float t, u, v;      // hit
-  uint32_t tri;       // index into S.tris
+  uint32_t tri;       // 2 * leaf slot + half: index into S.shade_recs
 };
 struct ShadeOut {
   vec3 emitted;        // to add to the path radiance now (already multiplied by attenuation and MIS weight)

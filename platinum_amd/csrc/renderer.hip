@@ -75,7 +75,7 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
   for (uint32_t b = 0; b < S.max_bounces; b++) {
     {
       ScopedTimer t(r, K_CLOSEST);
-      launch_trace_closest(s, r->trace_grid, S, r->path_state(cur), r->hit.p, seg, (uint32_t)cur, ctr, b, r->spill.p, hitlog, S.width * S.height, count);
+      launch_trace_closest(s, r->closest_grid, S, r->path_state(cur), r->hit.p, seg, (uint32_t)cur, ctr, b, r->spill.p, hitlog, S.width * S.height, count);
     }
     {
       ScopedTimer t(r, K_SHADE);
@@ -85,7 +85,7 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
     }
     if (mis) {
       ScopedTimer t(r, K_SHADOW);
-      launch_trace_shadow(s, r->trace_grid, S, r->shadow_queue(), r->Lbuf.p, seg, ctr, b, r->spill.p, count);
+      launch_trace_shadow(s, r->shadow_grid, S, r->shadow_queue(), r->Lbuf.p, seg, ctr, b, r->spill.p, count);
     }
     cur ^= 1;
   }
@@ -218,7 +218,8 @@ int dev_create(const pt_create_info* info, int device_ordinal, pt_renderer** out
   if (const char* e = getenv("PTAMD_SEG_BANDS")) r->seg_bands = (uint32_t)std::max(1, std::min(64, atoi(e)));
   if (const char* e = getenv("PTAMD_TWO_LEVEL")) r->two_level_override = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("PTAMD_BLOCKS_PER_CU")) r->blocks_per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));
-  if (const char* e = getenv("PTAMD_TRACE_BLOCKS_PER_CU")) r->trace_blocks_per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));
+  if (const char* e = getenv("PTAMD_CLOSEST_BLOCKS_PER_CU")) r->closest_blocks_per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));
+  if (const char* e = getenv("PTAMD_SHADOW_BLOCKS_PER_CU")) r->shadow_blocks_per_cu = (uint32_t)std::max(1, std::min(8, atoi(e)));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, r->device) == hipSuccess) r->num_cu = prop.multiProcessorCount;
   int rc = PT_OK;
@@ -299,7 +300,8 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
     const int rc = build_host_scene(scene, p, r->lut_w_E, r->lut_w_Eavg, &hs, &err);
     if (rc != PT_OK) return fail(rc, err);
   }
-  if (hs.tri_count >= (1u << 28)) return fail(PT_ERR_UNSUPPORTED, "more than 2^28 flattened triangles (the hit record keeps 28 bits for the triangle)");
+  if (hs.tri_count >= (1u << 27)) return fail(PT_ERR_UNSUPPORTED, "more than 2^27 flattened triangles (the hit record keeps 28 bits for 2 * leaf slot + half)");
+  if (hs.instances.size() >= (1u << kSlotInstBits)) return fail(PT_ERR_UNSUPPORTED, "more than 2^26 instances (a leaf slot keeps 26 bits for the instance)");
   phase("host flatten + light table");
   r->instance_count = (uint32_t)hs.instances.size();
   r->tri_count = hs.tri_count;
@@ -395,7 +397,15 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
       be = build_two_level(r->stream, S, hs.meshes.data(), (uint32_t)hs.meshes.size(), r->instance_count, r->tri_count,
                            (uint32_t)(kLdsStack + kSpillStack), &r->bvh_scratch, &r->bvh);
     } else {
-      be = build_lbvh(r->stream, S, r->instance_count, r->tri_count, (uint32_t)(kLdsStack + kSpillStack), &r->bvh_scratch, &r->bvh);
+      // leaf slots: two consecutive triangles of a mesh that share an edge go into ONE slot ($PTAMD_NO_PAIRS: one triangle per slot, as r3 had it)
+      build_primitives(&hs, getenv("PTAMD_NO_PAIRS") == nullptr);
+      PT_HIP(r->prim_tri_d.upload(hs.prim_tri));
+      PT_HIP(r->mesh_prim_base_d.upload(hs.mesh_prim_base));
+      PT_HIP(r->inst_prim_base_d.upload(hs.inst_prim_base));
+      PrimTables prims;
+      prims.prim_tri = r->prim_tri_d.p; prims.mesh_prim_base = r->mesh_prim_base_d.p; prims.inst_prim_base = r->inst_prim_base_d.p;
+      prims.slot_count = hs.prim_count;
+      be = build_lbvh(r->stream, S, prims, r->instance_count, (uint32_t)(kLdsStack + kSpillStack), &r->bvh_scratch, &r->bvh);
     }
     if (be != hipSuccess)
       return fail(be == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP, std::string("LBVH build failed: ") + hipGetErrorString(be));
@@ -409,6 +419,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
       return fail(PT_ERR_UNSUPPORTED, "BVH too deep for the traversal stack (degenerate geometry: thousands of coincident triangles?)");
     S.nodes = r->bvh.nodes;
     S.tris = r->bvh.tris;
+    S.slot_count = r->slot_count = r->bvh.slot_count;
     S.root_ref = r->bvh.root_ref;
     S.node_count = r->bvh.node_count;
     S.two_level = r->two_level ? 1u : 0u;
@@ -417,7 +428,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
     S.mesh_trav = r->bvh.mesh_trav;
   }
   phase("acceleration structure");
-  PT_HIP(r->shade_recs.alloc(r->tri_count));
+  PT_HIP(r->shade_recs.alloc(std::max<size_t>(1, 2 * (size_t)r->slot_count)));  // entry 2 * slot + half
   S.shade_recs = r->shade_recs.p;
   launch_shade_records(r->stream, S, r->shade_recs.p);
   PT_HIP(r->light_recs.alloc(std::max<size_t>(1, r->lights.size())));
@@ -451,7 +462,8 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   const uint32_t sif = r->samples_in_flight;
   r->grid = (uint32_t)r->num_cu * r->blocks_per_cu;                 // raygen, hit records: 256-thread blocks
   r->shade_grid = (uint32_t)r->num_cu * shade_blocks_per_cu();     // as many blocks as k_shade's registers / LDS keep resident
-  r->trace_grid = r->two_level ? (uint32_t)r->num_cu * trace_blocks_per_cu_two_level() : (uint32_t)r->num_cu * r->trace_blocks_per_cu;
+  r->closest_grid = (uint32_t)r->num_cu * (r->two_level ? trace_blocks_per_cu_two_level() : r->closest_blocks_per_cu);
+  r->shadow_grid = (uint32_t)r->num_cu * (r->two_level ? trace_blocks_per_cu_two_level() : r->shadow_blocks_per_cu);
   r->nstats = std::max(r->grid * (kBlock / 64), r->shade_grid * (shade_block_threads() / 64));
   for (int k = 0; k < 2; k++) {
     PT_HIP(r->st_rayO[k].alloc(r->capacity)); PT_HIP(r->st_rayD[k].alloc(r->capacity));
@@ -465,7 +477,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   PT_HIP(r->seg_poison.alloc(r->nseg));
   PT_HIP(r->wave_stats.alloc(r->nstats));
   for (int k = 0; k < 2; k++) PT_HIP(r->chunk_table[k].alloc(r->capacity / 64));
-  PT_HIP(r->spill.alloc((size_t)r->trace_grid * trace_block_threads(r->two_level) * kSpillStack));  // per-thread HBM stack slab behind the LDS stack
+  PT_HIP(r->spill.alloc((size_t)std::max(r->closest_grid, r->shadow_grid) * trace_block_threads(r->two_level) * kSpillStack));  // per-thread HBM stack slab behind the LDS stack
   PT_HIP(hipMemsetAsync(r->wave_stats.p, 0, sizeof(WaveStats) * r->nstats, r->stream));
   if (p->external_accumulator) {
     r->acc = (vec4*)p->external_accumulator;
@@ -733,7 +745,7 @@ int dev_trace_primary(pt_renderer* r, uint32_t sample_idx, pt_hit_record* out) {
   seg.nsamples = 1;
   launch_raygen(s, r->grid, r->S, r->path_state(0), r->Lbuf.p, seg, r->ctr.p, sample_idx, 1);
   launch_chunk_tables(s, seg, 0, r->ctr.p, 0, 0, false);
-  launch_trace_closest(s, r->trace_grid, r->S, r->path_state(0), r->hit.p, seg, 0, r->ctr.p, 0, r->spill.p, nullptr, npix, false);
+  launch_trace_closest(s, r->closest_grid, r->S, r->path_state(0), r->hit.p, seg, 0, r->ctr.p, 0, r->spill.p, nullptr, npix, false);
   launch_hit_records(s, r->grid, r->S, r->path_state(0), r->hit.p, seg, rec.p);
   launch_fold_counters(s, r->ctr.p, r->totals.p + 1, seg, false);  // clears the per-wave statistics (scratch slot)
   PT_HIP(hipGetLastError());
@@ -801,6 +813,7 @@ int dev_get_stats(pt_renderer* r, pt_stats* out) {
   PT_HIP(hipMemcpy(&t, r->totals.p, sizeof(Totals), hipMemcpyDeviceToHost));
   memset(out, 0, sizeof(*out));
   out->triangles = r->tri_count;
+  out->leaf_slots = r->slot_count;
   out->bvh_nodes = r->bvh.node_count;
   out->bvh_max_depth = r->bvh.depth4;
   out->samples_in_flight = r->samples_in_flight;

@@ -93,6 +93,7 @@ struct pt_renderer {
   DevBuf<ShadeRec> shade_recs;
   DevBuf<LightRec> light_recs;
   DevBuf<float> light_cdf;
+  DevBuf<uint32_t> prim_tri_d, mesh_prim_base_d, inst_prim_base_d;  // leaf-slot grouping of the one-BVH structure (host_scene.h build_primitives)
   DevBuf<InstanceTrav> inst_trav;   // two-level structure only
   bool two_level = false;
   int two_level_override = -1;      // $PTAMD_TWO_LEVEL: 0 / 1 force the choice, -1 = by instancing factor
@@ -105,7 +106,7 @@ struct pt_renderer {
   DeviceScene S{};
   pt_render_params params{};
   pt_constants constants{};
-  uint32_t instance_count = 0, tri_count = 0;
+  uint32_t instance_count = 0, tri_count = 0, slot_count = 0;
 
   // wavefront buffers
   uint32_t samples_in_flight = 0;
@@ -119,7 +120,7 @@ struct pt_renderer {
   pt_post_options post{};
   pt_tonemap_options tonemap{};
   DevBuf<uint32_t> render_target;  // RGBA8 (renderer_pt.cpp:832-835)
-  uint32_t trace_grid = 0, trace_blocks_per_cu = PT_TRACE_WAVES;
+  uint32_t closest_grid = 0, shadow_grid = 0, closest_blocks_per_cu = PT_CLOSEST_WAVES, shadow_blocks_per_cu = PT_SHADOW_WAVES;  // persistent trace grids, each sized for its kernel's occupancy
   uint32_t nseg = 0, tiles_per_seg = 1, seg_bands = 4, tiles_per_seg_override = 0, nstats = 0, seg_cap = 0, blocks_per_cu = 6, shade_grid = 0, refill_threshold = 48;
   DevBuf<BatchCounters> ctr;
   DevBuf<Totals> totals;
@@ -174,7 +175,7 @@ struct pt_renderer {
     free_scene();
     positions.release(); vdata.release(); indices.release(); slots.release(); meshes.release(); instances.release();
     materials.release(); lights_d.release(); tex_pixels.release(); textures.release(); env_alias_d.release(); scene_d.release(); shade_recs.release(); light_recs.release(); light_cdf.release();
-    inst_trav.release();
+    inst_trav.release(); prim_tri_d.release(); mesh_prim_base_d.release(); inst_prim_base_d.release();
     bvh_scratch.release();
     for (int k = 0; k < 2; k++) { st_rayO[k].release(); st_rayD[k].release(); st_att[k].release(); }
     seg_active[0].release(); seg_active[1].release(); seg_shadow.release(); seg_poison.release(); wave_stats.release(); chunk_table[0].release(); chunk_table[1].release(); gmon_buckets_d.release(); render_target.release();

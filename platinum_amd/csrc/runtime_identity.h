@@ -8,7 +8,7 @@
 //                    $ORIGIN as a different file and mapped as well: TWO HIP runtimes over TWO HSA runtimes.  The one initialised second
 //                    cannot acquire the process's GPU VM (the kernel driver binds it to the first runtime's DRM file) and reports
 //                    "no HIP GPUs".
-// A process must hold exactly one of each.  pt_create refuses to start otherwise, and says which objects collide.
+// A process must hold exactly one HIP runtime.  pt_create refuses to start otherwise, and says which objects collide.
 #pragma once
 #include <dlfcn.h>
 #include <link.h>
@@ -58,10 +58,13 @@ inline std::string join_paths(const std::vector<std::string>& v) {
   return s;
 }
 
-// "" when the process holds at most one HIP and one HSA runtime; otherwise what collides and what to do about it
+// "" when the process holds at most one HIP runtime; otherwise what collides and what to do about it.  (Two libhsa-runtime64 objects
+// under ONE HIP runtime are legitimate: rocprofv3's tool library links /opt/rocm's copy for its types and tables while the HIP runtime
+// that registers with it initialises its own — every profile of this repository was taken that way.  It is a second HIP runtime that
+// brings up a second HSA instance of its own.)
 inline std::string runtime_conflict() {
   const RuntimeObjects o = mapped_runtime_objects();
-  if (o.hip.size() <= 1 && o.hsa.size() <= 1) return std::string();
+  if (o.hip.size() <= 1) return std::string();
   std::string s = "two GPU runtimes are mapped into this process (HIP: " + join_paths(o.hip) + "; HSA: " + join_paths(o.hsa) +
                   "): only the one that initialises first gets the GPU.  PyTorch's wheel bundles its own copies under torch/lib; "
                   "load it BEFORE libptamd.so (the library then binds to torch's copy by soname), or load libptamd.so through "

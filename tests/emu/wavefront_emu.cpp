@@ -18,7 +18,7 @@ using namespace pt;
 
 namespace {
 
-static unsigned long long g_nodes = 0, g_tris = 0, g_rays = 0;  // traversal statistics of emu_debug_sample (experiments)
+static unsigned long long g_nodes = 0, g_tris = 0, g_rays = 0, g_leaves = 0;  // traversal statistics of emu_debug_sample (experiments)
 
 struct Emu {
   HostScene hs;
@@ -38,9 +38,15 @@ struct Emu {
   std::vector<std::vector<uint32_t>> groups;  // multi-triangle leaves of the probe trees: ref = kLeafBit | 0x40000000 | group index
 };
 
+// The r3 probes below walk trees whose leaf slots hold ONE triangle (they are only run without EMU_PAIRS): triangle A of a slot
+static bool probe_intersect(vec3 o, vec3 d, float tmin, float tmax, const TriRec& tr, float* t, float* u, float* v) {
+  const vec3 v0 = v3(tr.q0[0], tr.q0[1], tr.q0[2]), v1 = v3(tr.q1[0], tr.q1[1], tr.q1[2]), v2 = v3(tr.q2[0], tr.q2[1], tr.q2[2]);
+  return intersect_triangle(o, d, tmin, tmax, v0, v1 - v0, v2 - v0, t, u, v);
+}
+
 Box3 tri_box(const TriRec& t, const vec3& v1, const vec3& v2) {
   Box3 b;
-  const float* a = t.v0; const float* p1 = &v1.x; const float* p2 = &v2.x;
+  const float* a = t.q0; const float* p1 = &v1.x; const float* p2 = &v2.x;
   for (int k = 0; k < 3; k++) { b.lo[k] = std::min(a[k], std::min(p1[k], p2[k])); b.hi[k] = std::max(a[k], std::max(p1[k], p2[k])); }
   return b;
 }
@@ -364,7 +370,7 @@ static RayHit wide_closest(const Emu& e, int store, int rule, vec3 o, vec3 d, fl
           const uint32_t ti = grp ? list[g] : (n.ref[k] & ~kLeafBit);
           const TriRec& tr = S.tris[ti];
           float t, u, v;
-          if (intersect_triangle(o, d, tmin, best.t, tr, &t, &u, &v) && (t < best.t || best.tri == kInvalidRef || tr.gid < best.gid)) { best.t = t; best.u = u; best.v = v; best.tri = ti; best.gid = tr.gid; }
+          if (probe_intersect(o, d, tmin, best.t, tr, &t, &u, &v) && (t < best.t || best.tri == kInvalidRef || tr.gid_a < best.gid)) { best.t = t; best.u = u; best.v = v; best.tri = 2 * ti; best.gid = tr.gid_a; }
         }
       } else inner[ni++] = {tn, n.ref[k]};
     }
@@ -396,21 +402,43 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
     if (!prime) continue;
     e->halton.push_back(make_halton_entry(c));
   }
-  // flatten to world space (same sequence as lbvh.hip k_flatten)
+  // flatten to world space (same sequence as lbvh.hip k_flatten): one record per leaf slot = one triangle, or with EMU_PAIRS=1 (what the
+  // device build does by default) two consecutive triangles of a mesh that share an edge
+  build_primitives(&e->hs, getenv("EMU_PAIRS") != nullptr);
   std::vector<TriRec> tmp; std::vector<Box3> boxes;
   for (uint32_t i = 0; i < e->hs.instances.size(); i++) {
     const InstanceInfo& in = e->hs.instances[i];
     const MeshInfo& m = e->hs.meshes[in.mesh];
     const Xform X = load_xform(in);
-    for (uint32_t t = 0; t < m.tri_count; t++) {
+    for (uint32_t k = e->hs.mesh_prim_base[in.mesh]; k < e->hs.mesh_prim_base[in.mesh + 1]; k++) {
+      const uint32_t t = e->hs.prim_tri[k] & ~kPrimPairBit;
+      const bool pair = (e->hs.prim_tri[k] & kPrimPairBit) != 0;
       const uint32_t* idx = &e->hs.indices[3 * (size_t)(m.tri_base + t)];
-      vec3 v0 = transformPoint(ld3(e->hs.positions[m.vertex_base + idx[0]]), X);
-      vec3 v1 = transformPoint(ld3(e->hs.positions[m.vertex_base + idx[1]]), X);
-      vec3 v2 = transformPoint(ld3(e->hs.positions[m.vertex_base + idx[2]]), X);
-      vec3 e1 = v1 - v0, e2 = v2 - v0;
-      TriRec r; r.v0[0] = v0.x; r.v0[1] = v0.y; r.v0[2] = v0.z; r.e1[0] = e1.x; r.e1[1] = e1.y; r.e1[2] = e1.z;
-      r.e2[0] = e2.x; r.e2[1] = e2.y; r.e2[2] = e2.z; r.inst = i; r.prim = t; r.gid = in.tri_global_base + t;
-      tmp.push_back(r); boxes.push_back(tri_box(r, v1, v2));
+      const vec3 v0 = transformPoint(ld3(e->hs.positions[m.vertex_base + idx[0]]), X);
+      const vec3 v1 = transformPoint(ld3(e->hs.positions[m.vertex_base + idx[1]]), X);
+      const vec3 v2 = transformPoint(ld3(e->hs.positions[m.vertex_base + idx[2]]), X);
+      vec3 v3_ = v0;
+      TriRec r;
+      uint32_t bcode = 0;
+      r._pad = 0; r.gid_b = kInvalidRef;
+      r.gid_a = ((in.tri_global_base + t) << 2) | material_class(e->hs.materials[in.material_base + e->hs.slots[m.tri_base + t]]);
+      if (pair) {
+        for (int c = 0; c < 3; c++) {
+          const uint32_t ib = idx[3 + c];
+          uint32_t code = 3u;
+          if (ib == idx[0]) code = 0u; else if (ib == idx[1]) code = 1u; else if (ib == idx[2]) code = 2u;
+          else v3_ = transformPoint(ld3(e->hs.positions[m.vertex_base + ib]), X);
+          bcode |= code << (2 * c);
+        }
+        r.gid_b = ((in.tri_global_base + t + 1) << 2) | material_class(e->hs.materials[in.material_base + e->hs.slots[m.tri_base + t + 1]]);
+      }
+      r.inst_code = i | (bcode << kSlotInstBits);
+      r.q0[0] = v0.x; r.q0[1] = v0.y; r.q0[2] = v0.z; r.q1[0] = v1.x; r.q1[1] = v1.y; r.q1[2] = v1.z;
+      r.q2[0] = v2.x; r.q2[1] = v2.y; r.q2[2] = v2.z; r.q3[0] = v3_.x; r.q3[1] = v3_.y; r.q3[2] = v3_.z;
+      Box3 b = tri_box(r, v1, v2);
+      const float* p3 = &v3_.x;
+      for (int c = 0; c < 3; c++) { b.lo[c] = std::min(b.lo[c], p3[c]); b.hi[c] = std::max(b.hi[c], p3[c]); }
+      tmp.push_back(r); boxes.push_back(b);
     }
   }
   std::vector<uint32_t> order(tmp.size());
@@ -472,10 +500,14 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
   memset(&S, 0, sizeof(S));
   S.positions = e->hs.positions.data(); S.vdata = e->hs.vdata.data(); S.indices = e->hs.indices.data(); S.slots = e->hs.slots.data();
   S.meshes = e->hs.meshes.data(); S.instances = e->hs.instances.data(); S.materials = e->hs.materials.data();
-  S.lights = e->hs.lights.data(); S.nodes = e->nodes.data(); S.tris = e->tris.data(); S.tri_count = (uint32_t)e->tris.size();
+  S.lights = e->hs.lights.data(); S.nodes = e->nodes.data(); S.tris = e->tris.data(); S.tri_count = e->hs.tri_count; S.slot_count = (uint32_t)e->tris.size();
   S.root_ref = root; S.wide6 = wide6 ? 1u : 0u; S.halton = e->halton.data();
-  e->shade_recs.resize(e->tris.size());
-  for (size_t i = 0; i < e->tris.size(); i++) e->shade_recs[i] = make_shade_rec(S, e->tris[i]);
+  e->shade_recs.assign(2 * e->tris.size(), ShadeRec{});   // entry 2 * slot + half
+  for (size_t i = 0; i < 2 * e->tris.size(); i++) {
+    const TriRec& tr = e->tris[i >> 1];
+    const uint32_t gid = (i & 1) ? tr.gid_b : tr.gid_a;
+    if (gid != kInvalidRef) e->shade_recs[i] = make_shade_rec(S, tr.inst_code & kSlotInstMask, (gid >> 2) - e->hs.instances[tr.inst_code & kSlotInstMask].tri_global_base);
+  }
   S.shade_recs = e->shade_recs.data();
   e->light_recs.resize(e->hs.lights.size());
   for (size_t i = 0; i < e->hs.lights.size(); i++) e->light_recs[i] = make_light_rec(S, e->hs.lights[i]);
@@ -519,8 +551,8 @@ static RayHit probe_closest(const DeviceScene& S, vec3 o, vec3 d, float tmin, fl
     (*tris)++;
     const TriRec& tr = S.tris[ti];
     float t, u, v;
-    if (!intersect_triangle(o, d, tmin, best.t, tr, &t, &u, &v)) return;
-    if (t < best.t || best.tri == kInvalidRef || tr.gid < best.gid) { best.t = t; best.u = u; best.v = v; best.tri = ti; best.gid = tr.gid; }
+    if (!probe_intersect(o, d, tmin, best.t, tr, &t, &u, &v)) return;
+    if (t < best.t || best.tri == kInvalidRef || tr.gid_a < best.gid) { best.t = t; best.u = u; best.v = v; best.tri = 2 * ti; best.gid = tr.gid_a; }
   };
   if (S.root_ref & kLeafBit) { test_tri(S.root_ref & ~kLeafBit); return best; }
   std::vector<std::pair<uint32_t, float>> stack;
@@ -579,7 +611,7 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
         TraversalCount tc;
         const float ir = S.has_alpha ? Halton{halton_table(S.halton), rg.offset, dim}.sample1d() : 0.0f;
         RayHit hit = traverse<false, true>(S, o, d, 1e-3f, kInf, ir, st, &tc);
-        g_nodes += tc.nodes; g_tris += tc.tris; g_rays++;
+        g_nodes += tc.nodes; g_tris += tc.tris; g_leaves += tc.leaves; g_rays++;
         if (!e->wide[8].empty() && !S.has_alpha) {
           for (int N : {4, 6, 8})
             for (int rule = 0; rule < 3; rule++) {
@@ -599,7 +631,7 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
           g_probe.rays++;
           if (a.tri != hit.tri || c.tri != hit.tri || a.t != hit.t || c.t != hit.t) g_probe.mismatch++;
         }
-        if (hits && hit.tri != kInvalidRef) { hits[((size_t)b * NP + pid) * 2] = S.tris[hit.tri].inst; hits[((size_t)b * NP + pid) * 2 + 1] = S.tris[hit.tri].prim; }
+        if (hits && hit.tri != kInvalidRef) triangle_ids(S, hit.tri, &hits[((size_t)b * NP + pid) * 2], &hits[((size_t)b * NP + pid) * 2 + 1]);
         if (hit.tri == kInvalidRef) {
           if (S.env_texture >= 0) L = L + stage_miss(S, d, att, b, lastPdf, lastSpec);
           L = L + att * 0.0f;  // attenuation * backgroundColor (kernel.metal:311 / :541): NaN for a throughput that is not finite
@@ -622,6 +654,76 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
     }
 }
 
+// ---- the CPU leg of the benchmark: "the same __host__ __device__ kernels built for the host, all host cores" ----
+// Renders samples [first, first + ns) of every pixel with the product's own stage functions (stage_raygen, traverse<> over the product's
+// 6-wide node form, stage_shade, stage_miss: platinum_amd/csrc/pt_*.h compiled by g++ with -ffp-contract=off), std::thread workers taking
+// 16x16 pixel tiles from one atomic cursor, and folds them into `acc` as k_accumulate does (running mean in sample order, n0 samples
+// already there).  Per path it is the kernel sequence of kernels.hip; what the host has no use for (queues, compaction, chunk claims) is
+// the scheduler, not the arithmetic.  bench.py times this call only (the scene / BVH set-up is emu_create).
+}  // extern "C"  (std::thread / std::atomic below)
+#include <atomic>
+#include <thread>
+extern "C" {
+static vec3 emu_path(const Emu* e, uint32_t x, uint32_t y, uint32_t sample, uint32_t* lds, uint32_t* spill, uint32_t* pend) {
+  const DeviceScene& S = e->S;
+  const uint32_t B = S.max_bounces;
+  RayGenOut rg = stage_raygen(S, x, y, sample);
+  vec3 o = rg.o, d = rg.d, att = v3(1.0f), L = v3(0.0f);
+  float lastPdf = 0.0f; bool lastSpec = false; uint32_t dim = rg.dim;
+  for (uint32_t b = 0; b < B; b++) {
+    TraversalStack st; st.lds = lds; st.pend = pend; st.lds_stride = 1; st.spill = spill; st.spill_stride = 1;
+    TraversalCount tc;
+    const float ir = S.has_alpha ? Halton{halton_table(S.halton), rg.offset, dim}.sample1d() : 0.0f;
+    const RayHit hit = traverse<false, false>(S, o, d, 1e-3f, kInf, ir, st, &tc);
+    if (hit.tri == kInvalidRef) {
+      if (S.env_texture >= 0) L = L + stage_miss(S, d, att, b, lastPdf, lastSpec);
+      L = L + att * 0.0f;
+      break;
+    }
+    const vec4 qO{o.x, o.y, o.z, lastPdf}, qD{d.x, d.y, d.z, 0.0f};
+    ShadeIn in; in.o = o; in.d = d; in.att = att; in.rayO = &qO; in.rayD = &qD; in.lastSpecular = lastSpec; in.offset = rg.offset;
+    in.dim = dim + 1; in.bounce = b; in.t = hit.t; in.u = hit.u; in.v = hit.v; in.tri = hit.tri;
+    const ShadeOut out = stage_shade(S, in);
+    if (out.has_emitted) L = L + out.emitted;
+    if (out.shadow) {
+      const RayHit sh = traverse<true, false>(S, out.shadow_o, out.shadow_d, 1e-3f, out.shadow_tmax, out.shadow_payload, st, &tc);
+      if (sh.tri == kInvalidRef) L = L + out.shadow_contrib;
+    }
+    if (!out.alive) break;
+    o = out.next_o; d = out.next_d; att = out.next_att; lastPdf = out.next_pdf; lastSpec = out.next_specular;
+    dim = out.dim & kMetaDimMask;
+  }
+  return L;
+}
+
+void emu_render(void* h, uint32_t first, uint32_t ns, float* acc /*W*H*4, running mean*/, uint32_t n0, uint32_t threads) {
+  const Emu* e = (const Emu*)h;
+  const uint32_t W = e->S.width, H = e->S.height, tx = (W + 15) / 16, ty = (H + 15) / 16;
+  std::atomic<uint32_t> cursor{0};
+  auto worker = [&]() {
+    std::vector<uint32_t> lds(std::max(kLdsStack, kLdsStack6) + 1), spill(kSpillStack), pend(std::max(kPendLeaves, kPendLeaves6) + 1);
+    for (;;) {
+      const uint32_t t = cursor.fetch_add(1);
+      if (t >= tx * ty) return;
+      const uint32_t x0 = (t % tx) * 16, y0 = (t / tx) * 16;
+      for (uint32_t y = y0; y < std::min(y0 + 16, H); y++)
+        for (uint32_t x = x0; x < std::min(x0 + 16, W); x++) {
+          float* a = acc + 4 * ((size_t)y * W + x);
+          for (uint32_t s = 0; s < ns; s++) {
+            vec3 L = emu_path(e, x, y, first + s, lds.data(), spill.data(), pend.data());
+            const uint32_t n = n0 + s;                 // k_accumulate (kernel.metal:672-684)
+            if (n > 0) { L = L + v3(a[0], a[1], a[2]) * (float)n; L = L / (float)(n + 1); }
+            a[0] = L.x; a[1] = L.y; a[2] = L.z; a[3] = 1.0f;
+          }
+        }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (uint32_t i = 1; i < std::max(1u, threads); i++) pool.emplace_back(worker);
+  worker();
+  for (auto& th : pool) th.join();
+}
+
 void emu_trace_primary(void* h, uint32_t sample, pt_hit_record* out) {
   Emu* e = (Emu*)h;
   const DeviceScene& S = e->S;
@@ -634,7 +736,7 @@ void emu_trace_primary(void* h, uint32_t sample, pt_hit_record* out) {
       const float ir = S.has_alpha ? Halton{halton_table(S.halton), rg.offset, rg.dim}.sample1d() : 0.0f;
       RayHit hit = traverse<false, false>(S, rg.o, rg.d, 1e-3f, kInf, ir, st, &tc);
       pt_hit_record& r = out[y * S.width + x];
-      if (hit.tri != kInvalidRef) { r.t = hit.t; r.u = hit.u; r.v = hit.v; r.instance = S.tris[hit.tri].inst; r.primitive = S.tris[hit.tri].prim; }
+      if (hit.tri != kInvalidRef) { r.t = hit.t; r.u = hit.u; r.v = hit.v; triangle_ids(S, hit.tri, &r.instance, &r.primitive); }
       else { r.t = r.u = r.v = 0; r.instance = r.primitive = -1; }
     }
 }
@@ -702,8 +804,8 @@ void emu_packet_probe(void* h, uint32_t sample, double out[6]) {
             if (!hitk[k][c]) continue;
             R& q = r[k];
             float t, u, v;
-            if (intersect_triangle(q.o, q.d, 1e-3f, q.best.t, tr, &t, &u, &v) && (t < q.best.t || q.best.tri == kInvalidRef || tr.gid < q.best.gid)) {
-              q.best.t = t; q.best.u = u; q.best.v = v; q.best.tri = ti; q.best.gid = tr.gid;
+            if (probe_intersect(q.o, q.d, 1e-3f, q.best.t, tr, &t, &u, &v) && (t < q.best.t || q.best.tri == kInvalidRef || tr.gid_a < q.best.gid)) {
+              q.best.t = t; q.best.u = u; q.best.v = v; q.best.tri = 2 * ti; q.best.gid = tr.gid_a;
             }
           }
         }
@@ -732,7 +834,8 @@ void emu_get_probe(unsigned long long out[6]) {
   out[0] = g_probe.nodes; out[1] = g_probe.nodes_cull; out[2] = g_probe.tris; out[3] = g_probe.tris_cull; out[4] = g_probe.rays; out[5] = g_probe.mismatch;
   g_probe = ProbeCounts{};
 }
-void emu_get_counts(unsigned long long out[3]) { out[0] = g_nodes; out[1] = g_tris; out[2] = g_rays; g_nodes = g_tris = g_rays = 0; }
+uint32_t emu_slot_count(void* h) { return ((Emu*)h)->S.slot_count; }
+void emu_get_counts(unsigned long long out[4]) { out[0] = g_nodes; out[1] = g_tris; out[2] = g_rays; out[3] = g_leaves; g_nodes = g_tris = g_rays = g_leaves = 0; }
 float emu_halton(void* h, uint32_t i, uint32_t d) { return halton(halton_table(((Emu*)h)->halton.data()), i, d); }
 
 }  // extern "C"

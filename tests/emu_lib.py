@@ -25,7 +25,7 @@ def lib():
     deps = [SRC] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-shared", "-o", LIB, SRC])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-shared", "-o", LIB, SRC])
     L = C.CDLL(LIB)
     L.emu_create.restype = C.c_void_p
     L.emu_create.argtypes = [C.POINTER(abi.SceneSnapshot), C.POINTER(abi.RenderParams), C.c_void_p, C.c_uint64]
@@ -35,6 +35,7 @@ def lib():
     L.emu_get_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.emu_debug_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.emu_trace_primary.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.emu_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
     L.emu_halton.restype = C.c_float
     L.emu_halton.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     _lib = L
@@ -79,6 +80,15 @@ class EmuScene:
         out = np.zeros(self.W * self.H, dtype=[("t", "f4"), ("u", "f4"), ("v", "f4"), ("instance", "i4"), ("primitive", "i4")])
         self.L.emu_trace_primary(self.h, sample_idx, out.ctypes.data)
         return out.reshape(self.H, self.W)
+
+    def render(self, first, ns, acc=None, acc_n0=0, threads=1):
+        """Samples [first, first + ns) of every pixel folded into the running mean `acc` (acc_n0 samples already in it): the product's
+        stage functions on `threads` host threads (bench.py's cpu_baseline, kind "same-kernels-host")."""
+        if acc is None:
+            acc = np.zeros((self.H, self.W, 4), dtype=np.float32)
+        assert acc.dtype == np.float32 and acc.flags["C_CONTIGUOUS"] and acc.shape == (self.H, self.W, 4)
+        self.L.emu_render(self.h, first, ns, acc.ctypes.data, acc_n0, threads)
+        return acc
 
     def halton(self, i, d):
         return self.L.emu_halton(self.h, i, d)

@@ -101,7 +101,7 @@ def test_library_and_torch_share_the_gpu_in_either_load_order(order):
     """The r3 failure (`torch.zeros(device="cuda:0")` -> "No HIP GPUs are available" after libptamd.so had initialised its own runtime)
     as a test: renderer created, THEN torch imported and used, then another renderer and the one-rank RCCL self-test - one process."""
     o = _run(order, "gpu")
-    assert o["hip_runtimes_mapped"] == 1 and o["hsa_runtimes_mapped"] == 1, o["all_mapped"]
+    assert o["hip_runtimes_mapped"] == 1, o["all_mapped"]
     assert o["torch_sum"] == 28.0
     assert o["create_after_torch"][0] == 0, o["create_after_torch"]
     if order == "lib-first":

@@ -69,13 +69,16 @@ def test_random_scene_fuzz_stage_functions(seed):
     assert np.array_equal(ro.view(np.uint32)[~nan], re_.view(np.uint32)[~nan])
 
 
+@pytest.mark.parametrize("pairs", [False, True])
 @pytest.mark.parametrize("name", ["cornell_sphere", "field3", "random5", "random11", "textured"])
-def test_six_wide_nodes_give_the_same_hits_and_radiance(name, monkeypatch):
+def test_six_wide_nodes_give_the_same_hits_and_radiance(name, pairs, monkeypatch):
     """r03: the one-BVH structure's 6-wide node form (pt_device.h BvhNode6: quantize_node6 / trav_node6 / the range entries of the leaf
     queue in pt_bvh.h) through the host harness, which builds it with the two properties the GPU builder gives it — a node's internal
     children are consecutive records, its leaf children consecutive triangles — against the oracle: the hits and the radiance do not
     depend on the structure that was walked (the GPU side of this is every `-m gpu` parity test: the device build is 6-wide by default)."""
     monkeypatch.setenv("EMU_WIDE6", "1")
+    if pairs:   # r4: leaf slots that hold two edge-sharing triangles (pt_device.h TriRec, host_scene.h pair_mesh_triangles)
+        monkeypatch.setenv("EMU_PAIRS", "1")
     sc = {"cornell_sphere": scenes.cornell_sphere_scene, "field3": lambda: scenes.field_scene(3), "random5": lambda: scenes.random_scene(5),
           "random11": lambda: scenes.random_scene(11), "textured": lambda: scenes.textured_scene()}[name]()
     p = make_params(64, 36, 1, 6)
@@ -86,6 +89,24 @@ def test_six_wide_nodes_give_the_same_hits_and_radiance(name, monkeypatch):
     nan = np.isnan(ro)
     assert np.array_equal(ho, he) and np.array_equal(nan, np.isnan(re_))
     assert np.array_equal(ro.view(np.uint32)[~nan], re_.view(np.uint32)[~nan])
+
+
+@pytest.mark.parametrize("name", ["cornell", "random7", "textured"])
+def test_threaded_host_render_of_the_shared_kernels_equals_the_oracle(name, monkeypatch):
+    """bench.py's cpu_baseline (kind "same-kernels-host"): emu_render runs the product's stage functions over 16x16
+    tiles on several std::thread workers and folds samples like k_accumulate.  The running mean it leaves must be the oracle's, bit for
+    bit, whatever the thread count and however the samples are split over calls."""
+    for k, v in (("EMU_MORTON", "1"), ("EMU_PLOC", "8"), ("EMU_WIDE6", "1")):   # the tree form bench.py asks for
+        monkeypatch.setenv(k, v)
+    sc = {"cornell": lambda: scenes.cornell_scene("bench"), "random7": lambda: scenes.random_scene(7), "textured": scenes.textured_scene}[name]()
+    p = make_params(72, 40, 5, 5)
+    o, e = oracle_lib.OracleScene(sc, p), emu_lib.EmuScene(sc, p)
+    want = o.render(0, 5)
+    a = e.render(0, 2, threads=3)
+    a = e.render(2, 3, acc=a, acc_n0=2, threads=5)
+    nan = np.isnan(want)
+    assert np.array_equal(nan, np.isnan(a)) and np.array_equal(want.view(np.uint32)[~nan], a.view(np.uint32)[~nan])
+    assert np.array_equal(e.render(0, 5, threads=1).view(np.uint32)[~nan], want.view(np.uint32)[~nan])
 
 
 def test_halton_fp32_division_boundaries_equal_oracle():

@@ -16,7 +16,7 @@ for name in which:
     rad = np.zeros((h,w,4),np.float32)
     e.L.emu_debug_sample(e.h, 0, rad.ctypes.data_as(C.c_void_p), None)
     out=(C.c_double*26)(); e.L.emu_get_wide(out)
-    cnt=(C.c_ulonglong*3)(); e.L.emu_get_counts(cnt)
+    cnt=(C.c_ulonglong*4)(); e.L.emu_get_counts(cnt)
     print(name, "rays %d mismatches %d | product 4-wide nodes/ray %.2f tris/ray %.2f" % (out[24], out[25], cnt[0]/cnt[2], cnt[1]/cnt[2]))
     i=0
     for N in (4,6,8):
