@@ -19,9 +19,15 @@
  *   int status() const                                     :59   the same bits: Status_Blocked/Ready/Busy/Done      :21-26
  *   std::pair<size_t, size_t> renderProgress() const       :61   the same
  *   size_t renderTime() const                              :63   the same (milliseconds)
- *   postProcessOptions() / tonemapOptions() / gmonOptions()
- *   / outputColorspace()                                :65-73   references / pointer to plain option structs the caller edits;
- *                                                                they are handed to the library whenever an image is asked for
+ *   std::vector<postprocess::PostProcessPass::Options>
+ *     postProcessOptions()                              :65      the same: one tagged pointer per pass (Exposure, ChromaticAberration,
+ *                                                                ContrastSaturation, ToneCurve, Vignette — the order of renderer_pt.cpp:343-352)
+ *                                                                into option structs this object owns (ptamd_postprocess.hpp)
+ *   postprocess::Tonemap::Options* tonemapOptions()     :67      the same: TonemapOptions with agxOptions.look / khrOptions / flimOptions / postTonemap
+ *   shaders_pt::GmonOptions& gmonOptions()              :71      pt_gmon_options& (the one member, `cap`)
+ *   color::Colorspace& outputColorspace()               :73      pt_colorspace& (the four chromaticity pairs a color::Colorspace is built from)
+ *        the caller edits them in place; they are flattened and handed to the library whenever an image is asked for (the reference's
+ *        passes read theirs when they are encoded)
  * Error behaviour as the reference's: nothing throws; a failing call prints "renderer_pt: <message>" to stderr (the
  * reference prints and asserts, renderer_pt.cpp:402, 1044) and leaves the object in Status_Blocked; lastError() keeps the text.
  * Threading as the reference's: one caller thread per Renderer.
@@ -37,6 +43,7 @@
 #include <vector>
 
 #include "ptamd.h"
+#include "ptamd_postprocess.hpp"
 
 namespace ptamd::renderer_pt {
 
@@ -129,11 +136,22 @@ public:
   }
   [[nodiscard]] size_t renderTime() const { return m_pt && m_started ? (size_t)pt_render_time_ms(m_pt) : 0; }  // :1037
 
-  // Option structs the UI edits every frame (renderer_pt.hpp:65-73; field names follow core/postprocessing.hpp).
-  [[nodiscard]] pt_post_options& postProcessOptions() { return m_postOptions; }
-  [[nodiscard]] constexpr pt_tonemap_options* tonemapOptions() { return &m_tonemapOptions; }
+  // Option structs the UI edits every frame (renderer_pt.hpp:65-73; types: ptamd_postprocess.hpp = core/postprocessing.hpp's shapes).
+  // One entry per post-process pass, in the order the reference runs them (renderer_pt.cpp:343-352); the UI switches on `type` and edits
+  // through the pointer (pt_viewport.cpp:259-335).
+  [[nodiscard]] std::vector<postprocess::PostProcessPass::Options> postProcessOptions() {
+    using P = postprocess::PostProcessPass;
+    std::vector<P::Options> options(5);
+    options[0].type = P::Type::Exposure; options[0].exposure = &m_exposure;
+    options[1].type = P::Type::ChromaticAberration; options[1].chromaticAberration = &m_chromaticAberration;
+    options[2].type = P::Type::ContrastSaturation; options[2].contrastSaturation = &m_contrastSaturation;
+    options[3].type = P::Type::ToneCurve; options[3].toneCurve = &m_toneCurve;
+    options[4].type = P::Type::Vignette; options[4].vignette = &m_vignette;
+    return options;
+  }
+  [[nodiscard]] constexpr postprocess::Tonemap::Options* tonemapOptions() { return &m_tonemap; }
   [[nodiscard]] constexpr pt_gmon_options& gmonOptions() { return m_gmonOptions; }
-  pt_colorspace& outputColorspace() { return m_tonemapOptions.output_space; }
+  pt_colorspace& outputColorspace() { return m_outputSpace; }
 
   // ---- what the reference fixes at compile time or does not have (ptamd.h "NEW") ----
   void setMaxBounces(uint32_t b) { m_maxBounces = b; }              // kernel.metal:5 MAX_BOUNCES = 50 (the default here too)
@@ -157,8 +175,9 @@ public:
 
 private:
   void create(const int* devices, uint32_t count, int first, const char* lutPath) noexcept {
-    pt_default_post_options(&m_postOptions);
-    pt_default_tonemap_options(&m_tonemapOptions);
+    pt_tonemap_options defaults;
+    pt_default_tonemap_options(&defaults);
+    m_outputSpace = defaults.output_space;   // Display P3 (renderer_pt.hpp:182)
     std::vector<int32_t> ord(devices, devices + count);
     pt_create_info ci{};
     ci.abi_version = PT_ABI_VERSION;
@@ -176,8 +195,11 @@ private:
   }
   // the option structs are pushed when an image is asked for (the reference's passes read them when they are encoded)
   bool pushOptions() const {
-    return check(pt_set_gmon_options(m_pt, &m_gmonOptions)) && check(pt_set_post_options(m_pt, &m_postOptions)) &&
-           check(pt_set_tonemap_options(m_pt, &m_tonemapOptions));
+    pt_post_options post;
+    pt_tonemap_options tonemap;
+    postprocess::flatten(m_exposure, m_chromaticAberration, m_contrastSaturation, m_toneCurve, m_vignette, &post);
+    postprocess::flatten(m_tonemap, m_outputSpace, &tonemap);
+    return check(pt_set_gmon_options(m_pt, &m_gmonOptions)) && check(pt_set_post_options(m_pt, &post)) && check(pt_set_tonemap_options(m_pt, &tonemap));
   }
 
   pt_renderer* m_pt = nullptr;
@@ -186,8 +208,13 @@ private:
   uint32_t m_selectedPipeline = uint32_t(Integrators::MIS);  // renderer_pt.hpp:98
   uint32_t m_maxBounces = 50, m_firstSample = 0, m_samplesInFlight = 0, m_nonfinitePolicy = 0, m_accelStructure = PT_ACCEL_AUTO;
   uint32_t m_samplesPerRender = 1;
-  pt_post_options m_postOptions{};
-  pt_tonemap_options m_tonemapOptions{};
+  postprocess::ExposureOptions m_exposure;                        // the passes' option structs (BasicPostProcessPass::m_options, postprocessing.hpp:304)
+  postprocess::ChromaticAberrationOptions m_chromaticAberration;
+  postprocess::ContrastSaturationOptions m_contrastSaturation;
+  postprocess::ToneCurveOptions m_toneCurve;
+  postprocess::VignetteOptions m_vignette;
+  postprocess::TonemapOptions m_tonemap;
+  pt_colorspace m_outputSpace{};
   pt_gmon_options m_gmonOptions{1.0f};
   mutable void* m_presentStream = nullptr;
   mutable std::string m_lastError;
