@@ -9,6 +9,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,7 +26,8 @@ struct HostScene {
   std::vector<InstanceInfo> instances;
   std::vector<pt_material_gpu> materials;
   std::vector<pt_area_light> lights;
-  std::vector<vec4> tex_pixels;          // every texture decoded to linear float4, back to back
+  std::vector<uint8_t> tex_data;         // every texture in its own format, each at a multiple of 16 bytes (pt_device.h TexInfo)
+  std::vector<float> tex_decode;         // unorm[256], srgb[256]: the floats 8-bit texels decode to
   std::vector<TexInfo> textures;
   std::vector<pt_alias_entry> env_alias;
   int32_t env_texture = -1;
@@ -155,56 +157,87 @@ inline vec3 from_pt(const pt_float3& v) { return v3(v.x, v.y, v.z); }
 
 
 // Texel decode (DESIGN.md "Texture contract"): UNORM8 -> i/255; sRGB8 colour channels through the piecewise sRGB EOTF
-// evaluated in double and rounded once; R8 -> (r,0,0,1); RG8 -> (r,g,0,1); RGBA32F verbatim.
+// evaluated in double and rounded once; R8 -> (r,0,0,1); RG8 -> (r,g,0,1); RGBA32F verbatim.  r4: the two 256-entry tables ARE the decode;
+// the texels stay in their format and go through them on fetch (pt_bsdf.h tex_fetch), on the device and here alike.
+constexpr size_t kTexDecodedBudget = 64u << 20;
+inline vec4 decode_texel(const float* tab, uint32_t format, const uint8_t* b, size_t i) {
+  const float* un = tab + kTexDecodeUnorm;
+  if (format == PT_TEX_RGBA32F) { vec4 v; memcpy(&v, b + 16 * i, 16); return v; }
+  if (format == PT_TEX_RGBA8_SRGB || format == PT_TEX_RGBA8) {
+    const float* col = tab + (format == PT_TEX_RGBA8_SRGB ? kTexDecodeSrgb : kTexDecodeUnorm);
+    return vec4{col[b[4 * i]], col[b[4 * i + 1]], col[b[4 * i + 2]], un[b[4 * i + 3]]};
+  }
+  if (format == PT_TEX_RG8) return vec4{un[b[2 * i]], un[b[2 * i + 1]], 0.0f, 1.0f};
+  return vec4{un[b[i]], 0.0f, 0.0f, 1.0f};
+}
+inline uint32_t tex_bytes_per_texel(uint32_t format) {
+  return format == PT_TEX_RGBA32F ? 16u : format == PT_TEX_RG8 ? 2u : format == PT_TEX_R8 ? 1u : 4u;
+}
 inline int decode_textures(const pt_scene_snapshot* scene, HostScene* out, std::string* err) {
-  float eotf[256];
+  out->tex_decode.resize(kTexDecodeEntries);
   for (int i = 0; i < 256; i++) {
     const double c = (double)i / 255.0;
-    eotf[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
+    out->tex_decode[kTexDecodeUnorm + i] = (float)i / 255.0f;
+    out->tex_decode[kTexDecodeSrgb + i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
   }
-  size_t total = 0;
+  size_t texels = 0, texels8 = 0;
   for (uint32_t t = 0; t < scene->texture_count; t++) {
     const pt_texture& tx = scene->textures[t];
     if (!tx.pixels || tx.width == 0 || tx.height == 0 || tx.width > 32768 || tx.height > 32768)
       return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "texture: null pixels or bad size");
     if (tx.format < PT_TEX_RGBA8_SRGB || tx.format > PT_TEX_RGBA32F) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "texture: unknown format");
-    total += (size_t)tx.width * tx.height;
+    texels += (size_t)tx.width * tx.height;
+    if (tx.format != PT_TEX_RGBA32F) texels8 += (size_t)tx.width * tx.height;
   }
-  if (total >= (1ull << 32)) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "textures: more than 2^32 texels");
-  out->tex_pixels.resize(total);
+  if (texels >= (1ull << 32)) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "textures: more than 2^32 texels");
+  // Storage policy.  Decoded float4 texels cost one dependent load less per tap (the table look-up) and 4-16x the bytes.  While the 8-bit
+  // textures of a scene decode into less than kTexDecodedBudget they are stored decoded (measured r4 on the atrium, whose four 64x64
+  // material textures are cache-resident either way: k_shade +7.6 %, k_trace_shadow +5 % with the tables in the path); a scene with real
+  // texture sets (a 2k x 2k RGBA8 map is 16 MB, 64 MB decoded) keeps them 8-bit so that they share the 256 MB Infinity Cache with the
+  // acceleration structure instead of evicting it.  $PTAMD_TEX_NATIVE=0 / 1 forces the choice (the parity tests run both).
+  bool native = texels8 * sizeof(vec4) > kTexDecodedBudget;
+  if (const char* e = getenv("PTAMD_TEX_NATIVE")) native = atoi(e) != 0;
+  size_t total = 0;
+  for (uint32_t t = 0; t < scene->texture_count; t++) {
+    const pt_texture& tx = scene->textures[t];
+    total = (total + 15u) / 16u * 16u + (size_t)tx.width * tx.height * (native ? tex_bytes_per_texel(tx.format) : 16u);
+  }
+  if (total >= (1ull << 36)) return hs_fail(err, PT_ERR_INVALID_ARGUMENT, "textures: more than 64 GB");
+  out->tex_data.assign((total + 15u) / 16u * 16u, 0);
   out->textures.resize(scene->texture_count);
   size_t base = 0;
   for (uint32_t t = 0; t < scene->texture_count; t++) {
     const pt_texture& tx = scene->textures[t];
     const size_t n = (size_t)tx.width * tx.height;
-    out->textures[t] = {(uint32_t)base, tx.width, tx.height, 0};
-    vec4* dst = &out->tex_pixels[base];
-    const uint8_t* b = (const uint8_t*)tx.pixels;
-    if (tx.format == PT_TEX_RGBA32F) {
-      memcpy(dst, tx.pixels, n * sizeof(vec4));
-    } else if (tx.format == PT_TEX_RGBA8_SRGB) {
-      for (size_t i = 0; i < n; i++) dst[i] = vec4{eotf[b[4 * i]], eotf[b[4 * i + 1]], eotf[b[4 * i + 2]], (float)b[4 * i + 3] / 255.0f};
-    } else if (tx.format == PT_TEX_RGBA8) {
-      for (size_t i = 0; i < n; i++)
-        dst[i] = vec4{(float)b[4 * i] / 255.0f, (float)b[4 * i + 1] / 255.0f, (float)b[4 * i + 2] / 255.0f, (float)b[4 * i + 3] / 255.0f};
-    } else if (tx.format == PT_TEX_RG8) {
-      for (size_t i = 0; i < n; i++) dst[i] = vec4{(float)b[2 * i] / 255.0f, (float)b[2 * i + 1] / 255.0f, 0.0f, 1.0f};
-    } else {
-      for (size_t i = 0; i < n; i++) dst[i] = vec4{(float)b[i] / 255.0f, 0.0f, 0.0f, 1.0f};
+    base = (base + 15u) / 16u * 16u;
+    if (native || tx.format == PT_TEX_RGBA32F) {
+      out->textures[t] = {(uint32_t)(base / 16u), tx.width, tx.height, tx.format};
+      memcpy(&out->tex_data[base], tx.pixels, n * tex_bytes_per_texel(tx.format));
+      base += n * tex_bytes_per_texel(tx.format);
+    } else {  // decoded once, through the same tables a fetch of the 8-bit form goes through
+      const TexInfo as_given{0u, tx.width, tx.height, tx.format};
+      out->textures[t] = {(uint32_t)(base / 16u), tx.width, tx.height, (uint32_t)PT_TEX_RGBA32F};
+      vec4* dst = reinterpret_cast<vec4*>(&out->tex_data[base]);
+      for (size_t i = 0; i < n; i++) dst[i] = decode_texel(out->tex_decode.data(), as_given.format, (const uint8_t*)tx.pixels, i);
+      base += n * sizeof(vec4);
     }
-    base += n;
   }
   return PT_OK;
+}
+// texel i of texture t as the linear float4 the sampler filters (the host twin of pt_bsdf.h tex_fetch)
+inline vec4 host_texel(const HostScene& hs, const TexInfo& t, size_t i) {
+  return decode_texel(hs.tex_decode.data(), t.format, &hs.tex_data[(size_t)t.offset16 * 16u], i);
 }
 
 // Environment::rebuildAliasTable (core/environment.cpp:5-91): importance = BT.709 luma of each texel, normalised to mean 1
 // (that is EnvironmentLight::alias[i].pdf), then Vose's alias method with the reference's two LIFO work lists.
-inline void build_env_alias(const vec4* px, size_t n, std::vector<pt_alias_entry>* table) {
+inline void build_env_alias(const HostScene& hs, const TexInfo& et, size_t n, std::vector<pt_alias_entry>* table) {
   table->assign(n, pt_alias_entry{0.0f, 0.0f, 0u});
   std::vector<float> q(n);
   float sum = 0.0f;
   for (size_t i = 0; i < n; i++) {
-    q[i] = dot(v3(px[i].x, px[i].y, px[i].z), v3(0.2126f, 0.7152f, 0.0722f));
+    const vec4 px = host_texel(hs, et, i);
+    q[i] = dot(v3(px.x, px.y, px.z), v3(0.2126f, 0.7152f, 0.0722f));
     sum += q[i];
   }
   const float scale = (float)n / sum;
@@ -269,7 +302,7 @@ inline int build_host_scene(const pt_scene_snapshot* scene, const pt_render_para
     const TexInfo& et = out->textures[out->env_texture];
     const size_t n = (size_t)et.w * et.h;
     if (scene->env_alias) out->env_alias.assign(scene->env_alias, scene->env_alias + n);  // the host's own table, verbatim
-    else build_env_alias(&out->tex_pixels[et.offset], n, &out->env_alias);
+    else build_env_alias(*out, et, n, &out->env_alias);
   }
   out->has_alpha = false;
 

@@ -62,6 +62,22 @@ struct ShadingContext {
 };
 // sampler(address::repeat, filter::linear) on a decoded float4 texture (filtering contract: DESIGN.md §2)
 PT_HD int tex_wrap(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
+// texel i of a texture as linear float4 (TexInfo: the stored format, decoded through the host's own tables)
+PT_HD vec4 tex_fetch(const DeviceScene& S, const TexInfo& t, size_t i) {
+  const uint8_t* base = S.tex_data + (size_t)t.offset16 * 16u;
+  if (t.format == PT_TEX_RGBA32F) return ldg(reinterpret_cast<const vec4*>(base) + i);
+  const float* unorm = S.tex_decode + kTexDecodeUnorm;
+  if (t.format == PT_TEX_RGBA8_SRGB || t.format == PT_TEX_RGBA8) {
+    const uint32_t v = ldg(reinterpret_cast<const uint32_t*>(base) + i);
+    const float* colour = S.tex_decode + (t.format == PT_TEX_RGBA8_SRGB ? kTexDecodeSrgb : kTexDecodeUnorm);
+    return vec4{ldg(&colour[v & 0xffu]), ldg(&colour[(v >> 8) & 0xffu]), ldg(&colour[(v >> 16) & 0xffu]), ldg(&unorm[v >> 24])};
+  }
+  if (t.format == PT_TEX_RG8) {
+    const uint16_t v = ldg(reinterpret_cast<const uint16_t*>(base) + i);
+    return vec4{ldg(&unorm[v & 0xffu]), ldg(&unorm[v >> 8]), 0.0f, 1.0f};
+  }
+  return vec4{ldg(&unorm[ldg(base + i)]), 0.0f, 0.0f, 1.0f};  // PT_TEX_R8
+}
 PT_HD vec4 tex_sample(const DeviceScene& S, int id, vec2 uv) {
   const TexInfo t = ldg(&S.textures[id]);
   const float fx = uv.x * (float)t.w - 0.5f, fy = uv.y * (float)t.h - 0.5f;
@@ -69,9 +85,8 @@ PT_HD vec4 tex_sample(const DeviceScene& S, int id, vec2 uv) {
   const float wx = fx - x0f, wy = fy - y0f;
   const int x0 = tex_wrap((int)x0f, (int)t.w), x1 = tex_wrap((int)x0f + 1, (int)t.w);
   const int y0 = tex_wrap((int)y0f, (int)t.h), y1 = tex_wrap((int)y0f + 1, (int)t.h);
-  const vec4* __restrict__ px = S.tex_pixels + t.offset;
-  const vec4 p00 = ldg(&px[(size_t)y0 * t.w + x0]), p01 = ldg(&px[(size_t)y0 * t.w + x1]);
-  const vec4 p10 = ldg(&px[(size_t)y1 * t.w + x0]), p11 = ldg(&px[(size_t)y1 * t.w + x1]);
+  const vec4 p00 = tex_fetch(S, t, (size_t)y0 * t.w + x0), p01 = tex_fetch(S, t, (size_t)y0 * t.w + x1);
+  const vec4 p10 = tex_fetch(S, t, (size_t)y1 * t.w + x0), p11 = tex_fetch(S, t, (size_t)y1 * t.w + x1);
   vec4 o;
   { const float a = p00.x + (p01.x - p00.x) * wx, b = p10.x + (p11.x - p10.x) * wx; o.x = a + (b - a) * wy; }
   { const float a = p00.y + (p01.y - p00.y) * wx, b = p10.y + (p11.y - p10.y) * wx; o.y = a + (b - a) * wy; }

@@ -177,8 +177,13 @@ constexpr int kHaltonDims = 620;
 struct Lut { const float* d; int w, h, depth; int lds; };  // lds != 0: `d` points at a copy a block staged in LDS (k_shade)
 struct LutSet { Lut E, Eavg, EMs, EavgMs, ETransIn, ETransOut; };  // the two *avgTrans tables are never sampled
 
-// ---- scene textures: decoded to linear float4 at upload, sampled with repeat + bilinear ---------------
-struct TexInfo { uint32_t offset, w, h, _pad; };  // offset into DeviceScene::tex_pixels
+// ---- scene textures: sampled with repeat + bilinear over LINEAR FLOAT texels (the texture contract) ---
+// r4: 8-bit textures MAY stay 8-bit in HBM (4 / 2 / 1 bytes per texel instead of the 16 of a decoded float4) and are then decoded on fetch
+// through two 256-entry tables that hold the VERY floats the host decode produces (unorm[b] = (float)b / 255.0f; srgb[b] = the piecewise
+// EOTF evaluated in double and rounded once): the filter sees the same operands, the result is the same bit for bit.  host_scene.h
+// decode_textures picks the form per scene by footprint.  RGBA32F textures (the environment) are stored as they come.
+struct TexInfo { uint32_t offset16, w, h, format; };  // offset16: byte offset into DeviceScene::tex_data / 16; format: PT_TEX_*
+constexpr uint32_t kTexDecodeUnorm = 0, kTexDecodeSrgb = 256, kTexDecodeEntries = 512;
 
 struct Mat3 { vec3 c0, c1, c2; };
 PT_HD vec3 mul(const Mat3& m, vec3 v) { return (m.c0 * v.x + m.c1 * v.y) + m.c2 * v.z; }
@@ -208,7 +213,8 @@ struct DeviceScene {
   uint32_t node_count;     // records in nodes[] (a small two-level structure is staged in LDS by the trace kernels)
   const HaltonEntry* halton;
   LutSet luts;
-  const vec4* tex_pixels;
+  const uint8_t* tex_data;          // every texture in its own format, each starting at a multiple of 16 bytes
+  const float* tex_decode;          // kTexDecodeEntries floats: unorm[256], srgb[256]
   const TexInfo* textures;
   const pt_alias_entry* env_alias;  // EnvironmentLight::alias (pt_shader_defs.hpp:70-73)
   int32_t env_texture;              // -1: no environment light

@@ -319,7 +319,8 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   PT_HIP(r->instances.upload(hs.instances));
   PT_HIP(r->materials.upload(hs.materials));
   PT_HIP(r->lights_d.upload(r->lights));
-  PT_HIP(r->tex_pixels.upload(hs.tex_pixels));
+  PT_HIP(r->tex_data.upload(hs.tex_data));
+  PT_HIP(r->tex_decode.upload(hs.tex_decode));
   PT_HIP(r->textures.upload(hs.textures));
   PT_HIP(r->env_alias_d.upload(hs.env_alias));
   r->env_alias = std::move(hs.env_alias);
@@ -333,7 +334,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   S.camera = C.camera;
   S.idt = idt;
   S.width = p->width; S.height = p->height;
-  S.tex_pixels = r->tex_pixels.p; S.textures = r->textures.p; S.env_alias = r->env_alias_d.p;
+  S.tex_data = r->tex_data.p; S.tex_decode = r->tex_decode.p; S.textures = r->textures.p; S.env_alias = r->env_alias_d.p;
   S.env_texture = hs.env_texture;
   S.envLightCount = C.envLightCount;
   S.has_alpha = hs.has_alpha ? 1u : 0u;

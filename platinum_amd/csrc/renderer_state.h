@@ -97,7 +97,8 @@ struct pt_renderer {
   DevBuf<InstanceTrav> inst_trav;   // two-level structure only
   bool two_level = false;
   int two_level_override = -1;      // $PTAMD_TWO_LEVEL: 0 / 1 force the choice, -1 = by instancing factor
-  DevBuf<vec4> tex_pixels;            // all textures decoded to linear float4 (host_scene.h decode_textures)
+  DevBuf<uint8_t> tex_data;           // all textures in their own formats (host_scene.h decode_textures)
+  DevBuf<float> tex_decode;           // the 8-bit decode tables
   DevBuf<TexInfo> textures;
   DevBuf<pt_alias_entry> env_alias_d;
   std::vector<pt_alias_entry> env_alias;
@@ -174,7 +175,7 @@ struct pt_renderer {
   void release_all() {
     free_scene();
     positions.release(); vdata.release(); indices.release(); slots.release(); meshes.release(); instances.release();
-    materials.release(); lights_d.release(); tex_pixels.release(); textures.release(); env_alias_d.release(); scene_d.release(); shade_recs.release(); light_recs.release(); light_cdf.release();
+    materials.release(); lights_d.release(); tex_data.release(); tex_decode.release(); textures.release(); env_alias_d.release(); scene_d.release(); shade_recs.release(); light_recs.release(); light_cdf.release();
     inst_trav.release(); prim_tri_d.release(); mesh_prim_base_d.release(); inst_prim_base_d.release();
     bvh_scratch.release();
     for (int k = 0; k < 2; k++) { st_rayO[k].release(); st_rayD[k].release(); st_att[k].release(); }

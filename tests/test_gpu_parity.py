@@ -421,6 +421,21 @@ def test_textured_scene_hit_ids_and_radiance(gpu_renderer, variant, integrator):
     assert rc[..., :3].mean() > 1e-3
 
 
+@pytest.mark.parametrize("native", ["0", "1"])
+def test_textures_kept_eight_bit_in_hbm_give_the_same_image(gpu_renderer, native, monkeypatch):
+    """r4: 8-bit textures stored decoded (small texture sets) or kept 8-bit and decoded per tap through the host's tables (large ones):
+    $PTAMD_TEX_NATIVE forces the form; both must be the oracle's image bit for bit (base colour, roughness / metallic, normal map, cut-out
+    alpha in the trace kernels' alpha test, emission texture, float environment)."""
+    if "PTAMD_TEX_NATIVE" in os.environ:
+        pytest.skip("$PTAMD_TEX_NATIVE is preset for this session")
+    monkeypatch.setenv("PTAMD_TEX_NATIVE", native)
+    for sc in (scenes.textured_scene(), scenes.random_scene(1005, extras=True)):
+        p = _start(gpu_renderer, sc, 160, 90, 3, 6)
+        gpu_renderer.render(0)
+        assert _same_bits_or_both_nan(gpu_renderer.readbackAccumulator(), oracle_lib.OracleScene(sc, p).render(0, 3))
+    monkeypatch.delenv("PTAMD_TEX_NATIVE")
+
+
 def test_textured_scene_accumulator_and_golden(gpu_renderer):
     """The N3 golden fixture (tests/golden/n3_textured_golden.npz, minted from the oracle) through the product path."""
     import os

@@ -195,6 +195,22 @@ def test_stage_functions_bit_exact_vs_oracle_textured(kw, integrator):
     assert np.isfinite(ro).all() and ro[..., :3].mean() > 1e-3
 
 
+@pytest.mark.parametrize("native", ["0", "1"])
+def test_eight_bit_textures_decoded_on_fetch_give_the_same_bits(native, monkeypatch):
+    """r4 texture storage (host_scene.h decode_textures, pt_bsdf.h tex_fetch): 8-bit textures either decoded once to float4 or kept 8-bit and
+    decoded per tap through the unorm / sRGB tables.  Both forms ($PTAMD_TEX_NATIVE forces one) must give the oracle's radiance bit for
+    bit — every format is in this scene: sRGB8 base colour, RG8 roughness / metallic, RGBA8 normals, R8 transmission, RGBA32F environment."""
+    monkeypatch.setenv("PTAMD_TEX_NATIVE", native)
+    sc = scenes.random_scene(1003, extras=True)
+    for sc in (scenes.textured_scene(), scenes.random_scene(1003, extras=True)):
+        p = make_params(72, 40, 1, 6)
+        o, e = oracle_lib.OracleScene(sc, p), emu_lib.EmuScene(sc, p)
+        ro, ho = o.debug_sample(0)
+        re_, he = e.debug_sample(0)
+        nan = np.isnan(ro)
+        assert np.array_equal(ho, he) and np.array_equal(nan, np.isnan(re_)) and np.array_equal(ro.view(np.uint32)[~nan], re_.view(np.uint32)[~nan])
+
+
 def test_atrium_c5_class_scene_stage_functions_bit_exact():
     """BASELINE configs[4] stand-in (scenes.atrium_scene) at toy size: every N3 feature in one scene, 12 bounces."""
     sc = scenes.atrium_scene(env_size=(64, 32), columns=3)
