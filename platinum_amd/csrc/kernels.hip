@@ -197,13 +197,22 @@ __global__ void __launch_bounds__(1024) k_chunk_tables(Segments seg, uint32_t cu
 }
 
 // ---- the per-sample radiance buffer Lbuf -----------------------------------------------------------------------------
-// One vec4 per (pixel, sample in flight), laid out TILE-major: [8x8 tile][sample][lane = (y & 7) * 8 + (x & 7)].  The entries of one
-// tile under all samples are contiguous (64 KB at 64 samples in flight) and a segment's rays all belong to its tile(s): the shadow
-// kernel's read-modify-writes of a segment stay inside that window (a [sample][pixel] layout spread them over 64 planes 33 MB
-// apart: every access its own line).  `pid` in the path state IS this index.
+// One vec4 per (pixel, sample in flight), laid out TILE-major: the entries of one 8x8 tile under all samples are contiguous (128 KB at 128
+// samples in flight) and a segment's rays all belong to its tile(s): the shadow kernel's read-modify-writes of a segment stay inside that
+// window (a [sample][pixel] layout spread them over planes 33 MB apart: every access its own line).  `pid` in the path state IS this index.
+// Inside a tile the order is [pixel][sample] (r4, PT_PIXEL_MAJOR; r1-r3 had [sample][pixel]): the camera rays of a chunk are 64 SAMPLES OF
+// ONE PIXEL (k_raygen), so a chunk's 64 entries are 1 KB contiguous here too, and k_accumulate folds a pixel's samples from consecutive words.
+#ifndef PT_PIXEL_MAJOR
+#define PT_PIXEL_MAJOR 1
+#endif
 __device__ __forceinline__ uint32_t lbuf_index(uint32_t tile, uint32_t s, uint32_t nsamples, uint32_t lane) {
+#if PT_PIXEL_MAJOR
+  return (tile * 64u + lane) * nsamples + s;
+#else
   return (tile * nsamples + s) * 64u + lane;
+#endif
 }
+constexpr uint32_t kLbufSampleStride = PT_PIXEL_MAJOR ? 1u : 64u;  // distance between successive samples of one pixel
 __device__ __forceinline__ uint32_t lbuf_index_of_pixel(uint32_t p, uint32_t W, uint32_t s, uint32_t nsamples) {
   const uint32_t y = p / W, x = p - y * W, tilesX = (W + 7u) / 8u;
   return lbuf_index((y >> 3) * tilesX + (x >> 3), s, nsamples, (y & 7u) * 8u + (x & 7u));
@@ -226,9 +235,12 @@ __device__ __forceinline__ uint32_t pixel_of_pid_1spp(uint32_t pid, uint32_t W) 
 }
 
 // ---- raygen ------------------------------------------------------------------------------------------------------
-// One 8x8 pixel tile of one sample per wave iteration (a coherent camera-ray bundle).  Lanes outside the image
-// (partial edge tiles) are squeezed out.  Segment s = T consecutive tiles under all samples of the batch
-// (tile-major, sample-minor): consecutive chunks are the same 8x8 pixels under successive samples.
+// Segment s = T consecutive tiles under all samples of the batch.  One wave iteration emits 64 camera rays; lanes outside the image (partial
+// edge tiles) are squeezed out.  r4 (PT_PIXEL_MAJOR): the 64 rays of an iteration are consecutive SAMPLES OF ONE PIXEL (pixel-major,
+// sample-minor through the tile) where r1-r3 emitted one sample of the tile's 64 pixels.  The samples of a pixel differ by a sub-pixel
+// jitter, so the lanes of a bounce-0 chunk walk the same nodes and test the same triangles: their loads fall on the same addresses (one
+// L1 look-up instead of 64), they finish together, and their hits shade one triangle of one material.  Nothing else knows the order of a
+// segment's entries: a path finds its radiance entry through `pid`, which is computed here from (tile, pixel, sample).
 __global__ void __launch_bounds__(kBlock) k_raygen(DeviceScene S, PathState st, vec4* __restrict__ Lbuf, Segments seg,
                                                     BatchCounters* __restrict__ ctr, uint32_t first_sample,
                                                     uint32_t nsamples, uint32_t tilesX, uint32_t tilesY) {
@@ -240,20 +252,26 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DeviceScene S, PathState st, 
     const uint32_t first_tile = segment_first_tile(seg, sg);
     for (uint32_t k = 0; k < seg.tiles_per_seg * nsamples; k++) {
       const uint32_t tile = first_tile + k / nsamples;
-      const uint32_t s = k % nsamples;
       if (tile >= tiles) break;  // wave-uniform
+#if PT_PIXEL_MAJOR
+      const uint32_t r = (k % nsamples) * 64u + lane;   // ray r of the tile's 64 * nsamples, pixel-major
+      const uint32_t pl = r / nsamples, s = r - pl * nsamples;
+#else
+      const uint32_t pl = lane, s = k % nsamples;
+#endif
       const uint32_t ty = tile / tilesX;
-      const uint32_t x = (tile - ty * tilesX) * 8 + (lane & 7);
-      const uint32_t y = ty * 8 + (lane >> 3);
+      const uint32_t x = (tile - ty * tilesX) * 8 + (pl & 7);
+      const uint32_t y = ty * 8 + (pl >> 3);
       const bool valid = x < S.width && y < S.height;
       RayGenOut rg;
       if (valid) rg = stage_raygen(S, x, y, first_sample + s);
       const unsigned long long m = __ballot(valid);
       if (valid) {
         const uint32_t j = seg_slot(seg.nseg, sg, n_out + wave_prefix(m));
-        const uint32_t pid = lbuf_index(tile, s, nsamples, lane);  // = segment_lbuf_base(seg, sg) + k * 64 + lane
+        const uint32_t pid = lbuf_index(tile, s, nsamples, pl);
+        const uint32_t rel = pid - first_tile * nsamples * 64u;  // relative to the segment's window (segment_lbuf_base)
         st.rayO[j] = vec4{rg.o.x, rg.o.y, rg.o.z, 0.0f};
-        st.rayD[j] = vec4{rg.d.x, rg.d.y, rg.d.z, u2f((rg.dim & kMetaDimMask) | ((k * 64u + lane) << kMetaPidShift))};
+        st.rayD[j] = vec4{rg.d.x, rg.d.y, rg.d.z, u2f((rg.dim & kMetaDimMask) | (rel << kMetaPidShift))};
         st.att[j] = vec4{1.0f, 1.0f, 1.0f, u2f(rg.offset)};
         Lbuf[pid] = vec4{0.0f, 0.0f, 0.0f, 1.0f};
       }
@@ -706,6 +724,54 @@ k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments 
 }
 
 // ---- accumulate (kernel.metal:672-684): running mean, one sample at a time, in sample order --------------------------
+#if PT_PIXEL_MAJOR
+// One wave per 8x8 tile.  A tile's entries of Lbuf are [pixel][sample]: eight samples of eight pixels are 8 x 128 contiguous bytes, so the
+// wave loads blocks of 64 pixels x 8 samples fully coalesced (eight lanes per 128-byte line), turns them through LDS, and every lane then
+// folds the eight samples of ITS pixel in sample order — the running mean is a sequential recurrence per pixel (kernel.metal:672-684).
+__global__ void __launch_bounds__(kBlock) k_accumulate(vec4* __restrict__ acc, const vec4* __restrict__ Lbuf,
+                                                        uint32_t npixels, uint32_t width, uint32_t nsamples, uint32_t n0,
+                                                        uint32_t nonfinite_policy, BatchCounters* __restrict__ ctr) {
+  constexpr uint32_t kRow = 9;  // vec4 per pixel row in LDS (8 samples + 1 of padding against bank conflicts)
+  __shared__ vec4 stage[kBlock / 64][64 * kRow];
+  const uint32_t lane = wave_lane(), w = threadIdx.x >> 6;
+  const uint32_t height = npixels / width, tilesX = (width + 7u) / 8u, tiles = tilesX * ((height + 7u) / 8u);
+  const uint32_t tile = blockIdx.x * (kBlock / 64) + w;   // (every wave of the block runs the same number of rounds: the barriers are uniform)
+  const bool live = tile < tiles;
+  const uint32_t ty = live ? tile / tilesX : 0u, x = (tile - ty * tilesX) * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+  const bool inside = live && x < width && y < height;
+  const uint32_t p = y * width + x;
+  vec4 a = inside ? acc[p] : vec4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (uint32_t s0 = 0; s0 < nsamples; s0 += 8u) {
+    const uint32_t nb = nsamples - s0 < 8u ? nsamples - s0 : 8u;
+    __syncthreads();
+    if (live) {
+#pragma unroll
+      for (uint32_t i = 0; i < 8u; i++) {
+        const uint32_t px = i * 8u + (lane >> 3), j = lane & 7u;
+        if (j < nb) stage[w][px * kRow + j] = ld_stream(&Lbuf[(tile * 64u + px) * nsamples + s0 + j]);
+      }
+    }
+    __syncthreads();
+    if (inside) {
+      for (uint32_t j = 0; j < nb; j++) {
+        const vec4 v = stage[w][lane * kRow + j];
+        vec3 L = v3(v.x, v.y, v.z);
+        if (!(fabsf(L.x) <= 3.0e38f && fabsf(L.y) <= 3.0e38f && fabsf(L.z) <= 3.0e38f)) {  // NaN or inf
+          atomicAdd(&ctr->nonfinite, 1u);
+          if (nonfinite_policy == PT_NONFINITE_ZERO) L = v3(0.0f);
+        }
+        const uint32_t localFrameIdx = n0 + s0 + j;
+        if (localFrameIdx > 0) {
+          L = L + v3(a.x, a.y, a.z) * (float)localFrameIdx;
+          L = L / (float)(localFrameIdx + 1);
+        }
+        a = vec4{L.x, L.y, L.z, 1.0f};
+      }
+    }
+  }
+  if (inside) acc[p] = a;
+}
+#else
 __global__ void __launch_bounds__(kBlock) k_accumulate(vec4* __restrict__ acc, const vec4* __restrict__ Lbuf,
                                                         uint32_t npixels, uint32_t width, uint32_t nsamples, uint32_t n0,
                                                         uint32_t nonfinite_policy, BatchCounters* __restrict__ ctr) {
@@ -714,7 +780,7 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(vec4* __restrict__ acc, c
   vec4 a = acc[p];
   const uint32_t l0 = lbuf_index_of_pixel(p, width, 0, nsamples);
   for (uint32_t s = 0; s < nsamples; s++) {
-    const vec4 L4 = Lbuf[l0 + s * 64u];
+    const vec4 L4 = Lbuf[l0 + s * kLbufSampleStride];
     vec3 L = v3(L4.x, L4.y, L4.z);
     if (!(fabsf(L.x) <= 3.0e38f && fabsf(L.y) <= 3.0e38f && fabsf(L.z) <= 3.0e38f)) {  // NaN or inf
       atomicAdd(&ctr->nonfinite, 1u);
@@ -729,6 +795,7 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(vec4* __restrict__ acc, c
   }
   acc[p] = a;
 }
+#endif
 
 // ---- GMoN ---------------------------------------------------------------------------------------------
 // Accumulate into the bucket images exactly as the reference does with RendererFlags_GMoN: sample f goes to bucket
@@ -741,8 +808,17 @@ __global__ void __launch_bounds__(kBlock) k_accumulate_gmon(vec4* __restrict__ b
   const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= npixels) return;
   const uint32_t l0 = lbuf_index_of_pixel(p, width, 0, nsamples);
+  constexpr uint32_t kGroup = PT_PIXEL_MAJOR ? 8u : 1u;  // (as k_accumulate: one 128-byte line of samples per round of loads)
+  vec4 v[kGroup];
   for (uint32_t s = 0; s < nsamples; s++) {
-    const vec4 L4 = Lbuf[l0 + s * 64u];
+    if (s % kGroup == 0) {
+#pragma unroll
+      for (uint32_t j = 0; j < kGroup; j++)
+        if (s + j < nsamples) v[j] = ld_stream(&Lbuf[l0 + (s + j) * kLbufSampleStride]);
+    }
+    vec4 L4 = v[0];
+#pragma unroll
+    for (uint32_t j = 1; j < kGroup; j++) if (s % kGroup == j) L4 = v[j];
     vec3 L = v3(L4.x, L4.y, L4.z);
     if (!(fabsf(L.x) <= 3.0e38f && fabsf(L.y) <= 3.0e38f && fabsf(L.z) <= 3.0e38f)) {
       atomicAdd(&ctr->nonfinite, 1u);
@@ -942,8 +1018,14 @@ void launch_trace_shadow(hipStream_t s, uint32_t grid, const DeviceScene& S, Sha
 }
 void launch_accumulate(hipStream_t s, vec4* acc, const vec4* Lbuf, uint32_t npixels, uint32_t width, uint32_t nsamples, uint32_t n0,
                        uint32_t nonfinite_policy, BatchCounters* ctr) {
+#if PT_PIXEL_MAJOR
+  const uint32_t tiles = ((width + 7u) / 8u) * ((npixels / width + 7u) / 8u);   // one wave per 8x8 tile
+  hipLaunchKernelGGL(k_accumulate, dim3((tiles + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, s, acc, Lbuf, npixels, width, nsamples, n0,
+                     nonfinite_policy, ctr);
+#else
   hipLaunchKernelGGL(k_accumulate, dim3((npixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, acc, Lbuf, npixels, width, nsamples, n0,
                      nonfinite_policy, ctr);
+#endif
 }
 void launch_accumulate_gmon(hipStream_t s, vec4* buckets, const vec4* Lbuf, uint32_t npixels, uint32_t width, uint32_t nsamples, uint32_t n0,
                             uint32_t samples_per_bucket, uint32_t gmon_buckets, uint32_t bucket_base, uint32_t nonfinite_policy, BatchCounters* ctr) {
