@@ -9,7 +9,7 @@
 
 Units and corrections as MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports
 half of the bytes of wide coalesced streaming reads.  The factor is CALIBRATED here on the two kernels whose byte counts
-are known exactly: k_accumulate reads (S+1) * 16 B and writes 16 B per pixel, k_raygen writes 68 B per path.
+are known exactly: k_accumulate reads (S+1) * 16 B and writes 16 B per pixel, k_raygen writes 64 B per path.
 The traversal kernels read 64-B nodes / triangle slots as 16-B-per-lane gathers — a pattern the guide leaves uncalibrated;
 tools/calib_gather.hip calibrated it (profiles/r02_calib_gather.md): FETCH_SIZE is exact for it, so those kernels get x1."""
 import csv, glob, hashlib, json, os, shutil, sys
@@ -102,7 +102,7 @@ if "k_accumulate" in write and itw:
     raw = write["k_accumulate"]["WRITE_SIZE"][1] * 1024.0
     calib["write_factor_k_accumulate"] = expect / raw if raw else None
 if "k_raygen" in write and itw:
-    expect = itw["k_raygen"] * 68.0   # rayO 16 + rayD 16 + att 16 + pid 4 + Lbuf 16 per path (kernels.hip k_raygen)
+    expect = itw["k_raygen"] * 64.0   # rayO 16 + rayD 16 + att 16 + Lbuf 16 per path (kernels.hip k_raygen; the separate pid word went in r2)
     raw = write["k_raygen"]["WRITE_SIZE"][1] * 1024.0
     calib["write_factor_k_raygen"] = expect / raw if raw else None
     calib["k_raygen_write_bytes_expected"] = expect
