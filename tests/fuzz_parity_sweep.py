@@ -39,6 +39,10 @@ def main():
             flags = abi.FLAG_MULTISCATTER_GGX if seed % 5 else 0
             space = scenes.BT2020 if seed % 7 else scenes.BT709
             first, spp, sif = (seed % 13) * 3, 2 + seed % 4, 1 + seed % 5
+        if seed % 6 == 5:   # r4: big odd batches — a chunk of camera rays spans several pixels' samples (k_raygen, pixel-major), the accumulate tiles are ragged
+            spp = 33 + seed % 41
+            sif = spp if seed % 12 == 5 else 1 + (spp // 2)
+            w, h = (40, 27) if seed % 3 else (33, 18)
         r.selectKernel(integ)
         r.startRender(sc, (w, h), spp, workingSpace=space, flags=flags, max_bounces=B, first_sample=first, accel_structure=accel, samples_in_flight=sif)
         p = make_params(w, h, spp, B, flags=flags, integrator=integ, working_space=space, first_sample=first)
