@@ -26,7 +26,7 @@ def main():
     seed0, count = int(sys.argv[1]), int(sys.argv[2])
     extras = len(sys.argv) > 3 and sys.argv[3] == "extras"
     r = Renderer(device=0)
-    bad, t0 = [], time.time()
+    bad, grazing, t0 = [], [], time.time()
     for seed in range(seed0, seed0 + count):
         sc = scenes.random_scene(seed, extras=extras)
         integ = abi.INTEGRATOR_MIS if seed % 4 else abi.INTEGRATOR_SIMPLE
@@ -54,9 +54,18 @@ def main():
         r.render(0)
         checks.append(bool(same(r.readbackAccumulator(), o.render(first, spp))))
         if not all(checks):
-            bad.append([seed, checks])   # [constants, primary hits, per-bounce hit ids, per-sample radiance, accumulator]
+            # The contract defines a hit over ALL triangles; the oracle's BVH — like any BVH — may skip a triangle whose
+            # Moeller-Trumbore test accepts a near-parallel ray with a large error in t (the hit point lies outside the triangle's inflated box).
+            # Such a seed is re-checked against the oracle's BRUTE-FORCE traversal, the definition itself: equal there = the GPU follows the
+            # contract and the oracle's tree was the one that skipped (r4: seed 20341, a shadow ray leaving one half of a quad and grazing the other).
+            ob = oracle_lib.OracleScene(sc, p, use_bvh=False)
+            if checks[0] and checks[1] and bool(same(r.readbackAccumulator(), ob.render(first, spp))):
+                grazing.append(seed)
+            else:
+                bad.append([seed, checks])   # [constants, primary hits, per-bounce hit ids, per-sample radiance, accumulator]
     r.close()
-    print(json.dumps({"first": seed0, "extras": extras, "count": count, "mismatching_seeds": bad, "seconds": round(time.time() - t0, 1)}))
+    print(json.dumps({"first": seed0, "extras": extras, "count": count, "mismatching_seeds": bad,
+                      "equal_to_brute_force_but_not_to_the_oracles_bvh": grazing, "seconds": round(time.time() - t0, 1)}))
 
 
 if __name__ == "__main__":
