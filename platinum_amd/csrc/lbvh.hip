@@ -1,7 +1,8 @@
 // lbvh.hip — GPU LBVH build: replaces Metal's closed acceleration-structure build
 // (renderer_pt.cpp:244-294 makeAccelStruct, :653-749 rebuildAccelerationStructures).
 //
-//   k_flatten   instance x primitive -> world-space TriRec + AABB (fp32 transformPoint, the intersection contract)
+//   k_flatten   one leaf slot per thread: the world-space corners of one triangle, or of two consecutive triangles of a mesh that share an
+//               edge (host_scene.h pair_mesh_triangles), + the slot's AABB (fp32 transformPoint, the intersection contract)
 //   k_bounds    scene centroid bounds (wave reduce + ordered-int atomics)
 //   k_morton    63-bit Morton code of the AABB centre (21 bits / axis, cubic cells)
 //   radix sort  rocPRIM (hipcub::DeviceRadixSort::SortPairs, 64-bit keys)

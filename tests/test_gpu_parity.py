@@ -778,6 +778,33 @@ def test_radix_tree_fallback_builder_gives_the_same_image(gpu_renderer, monkeypa
     assert a.tobytes() == oracle_lib.OracleScene(sc, p).render(0, 2).tobytes()
 
 
+def test_leaf_slots_hold_two_triangles_and_the_one_triangle_form_gives_the_same_image(gpu_renderer, monkeypatch):
+    """r4: a 64-byte leaf slot holds two consecutive triangles of a mesh that share an edge (pt_device.h TriRec, host_scene.h pair_mesh_triangles):
+    the field's spheres and the Cornell shell pair up completely (slots = triangles / 2), $PTAMD_NO_PAIRS keeps one triangle per slot, and both forms
+    give the oracle's hits, per-sample radiance and image bit for bit — which triangles share a slot cannot change an answer."""
+    if "PTAMD_NO_PAIRS" in os.environ:
+        pytest.skip("$PTAMD_NO_PAIRS is preset for this session")
+    for sc in (scenes.field_scene(6), scenes.random_scene(9), scenes.textured_scene()):
+        w, h, B = 120, 68, 6
+        o = None
+        for pairs in (True, False):
+            if pairs:
+                monkeypatch.delenv("PTAMD_NO_PAIRS", raising=False)
+            else:
+                monkeypatch.setenv("PTAMD_NO_PAIRS", "1")
+            p = _start(gpu_renderer, sc, w, h, 3, B)
+            st = gpu_renderer.stats()
+            assert st.leaf_slots == st.triangles if not pairs else st.leaf_slots < st.triangles
+            o = o or oracle_lib.OracleScene(sc, p)
+            assert gpu_renderer.tracePrimary(1).tobytes() == o.trace_primary(1).tobytes()
+            rg, hg = gpu_renderer.debugSample(0)
+            rc, hc = o.debug_sample(0)
+            assert np.array_equal(hg, hc) and _same_bits_or_both_nan(rg, rc)
+            gpu_renderer.render(0)
+            assert _same_bits_or_both_nan(gpu_renderer.readbackAccumulator(), o.render(0, 3))
+    monkeypatch.delenv("PTAMD_NO_PAIRS", raising=False)
+
+
 def test_in_plane_shadow_ray_follows_the_brute_force_definition(gpu_renderer):
     """r4, found by the extended fuzz (seed 20341): a shadow ray that leaves one half of a flat quad INSIDE the quad's plane (a light flush with the
     wall).  Against the coplanar other half Moeller-Trumbore's determinant is rounding noise (1.4e-6 where |e1||e2| = 2.8; exact arithmetic says miss,
