@@ -661,7 +661,10 @@ struct Intersection { bool hit = false; float distance = 0; float u = 0, v = 0; 
 inline bool intersect_triangle(const Ray& ray, const WorldTri& tri, float* t_out, float* u_out, float* v_out) {
   const float3 p = cross(ray.direction, tri.e2);
   const float det = dot(tri.e1, p);
-  if (det == 0.0f) return false;
+  // r4 (intersection contract): a determinant that is rounding noise — a ray lying IN the triangle's plane, the sum e1 . p
+  // cancelling to below 1e-6 of its terms' magnitude — is a miss, not a coin toss: with `det == 0` alone such rays were accepted or rejected by
+  // noise, and the answer depended on which coplanar triangles a traversal happened to test (found by the extended fuzz: seeds 20341, 310601)
+  if (!(fabsf(det) > (1e-6f * ((fabsf(tri.e1.x) + fabsf(tri.e1.y)) + fabsf(tri.e1.z))) * ((fabsf(p.x) + fabsf(p.y)) + fabsf(p.z)))) return false;
   const float inv = 1.0f / det;
   const float3 s = ray.origin - tri.v0;
   const float u = dot(s, p) * inv;

@@ -19,13 +19,16 @@ struct RayHit {
   uint32_t gid;
 };
 
-// Moeller-Trumbore with a fixed operation order.  Returns true and (t,u,v) when det != 0, 0 <= u <= 1, 0 <= v,
+// Moeller-Trumbore with a fixed operation order.  Returns true and (t,u,v) when |det| > 1e-6 |e1|_1 |d x e2|_1, 0 <= u <= 1, 0 <= v,
 // u + v <= 1 and tmin <= t <= tmax.  (v0, e1 = v1 - v0, e2 = v2 - v0: world-space, the caller forms the edges.)
 PT_HD bool intersect_triangle(vec3 o, vec3 d, float tmin, float tmax, vec3 v0, vec3 e1, vec3 e2, float* t_out, float* u_out,
                               float* v_out) {
   const vec3 p = cross(d, e2);
   const float det = dot(e1, p);
-  if (det == 0.0f) return false;
+  // r4: a determinant that is rounding noise (a ray IN the triangle's plane: e1 . p cancels to below 1e-6 of its terms' magnitude) is a miss.
+  // With `det == 0` alone such rays were accepted or rejected by noise and the answer depended on which coplanar triangles a traversal
+  // happened to test — the one place where hits were not independent of the structure (fuzz seeds 20341, 310601).
+  if (!(fabsf(det) > (1e-6f * ((fabsf(e1.x) + fabsf(e1.y)) + fabsf(e1.z))) * ((fabsf(p.x) + fabsf(p.y)) + fabsf(p.z)))) return false;
   const float inv = 1.0f / det;
   const vec3 s = o - v0;
   const float u = dot(s, p) * inv;

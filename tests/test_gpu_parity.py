@@ -805,22 +805,44 @@ def test_leaf_slots_hold_two_triangles_and_the_one_triangle_form_gives_the_same_
     monkeypatch.delenv("PTAMD_NO_PAIRS", raising=False)
 
 
-def test_in_plane_shadow_ray_follows_the_brute_force_definition(gpu_renderer):
-    """r4, found by the extended fuzz (seed 20341): a shadow ray that leaves one half of a flat quad INSIDE the quad's plane (a light flush with the
-    wall).  Against the coplanar other half Moeller-Trumbore's determinant is rounding noise (1.4e-6 where |e1||e2| = 2.8; exact arithmetic says miss,
-    fp32 says hit at u = v = 0.5), so whether the ray counts as occluded depends on whether that triangle gets TESTED — the one place where the
-    contract's answer is not independent of the structure walked.  The contract defines a hit over ALL triangles: with two triangles
-    per leaf slot the partner is always tested, and the HIP path equals the oracle's BRUTE-FORCE traversal bit for bit; the oracle's own BVH (and
-    the r3 one-triangle slots) skip the partner and differ in that one pixel by the shadow ray's 3e-5 contribution."""
-    sc = scenes.random_scene(20341)
-    p = _start(gpu_renderer, sc, 96, 54, 3, 9)
+@pytest.mark.parametrize("seed,extras,two_level", [(20341, False, False), (104187, False, False), (50035, True, False), (310601, True, False), (310601, True, True)])
+def test_rays_in_a_triangles_plane_miss_it_whatever_structure_is_walked(gpu_renderer, seed, extras, two_level):
+    """r4, found by extending the fuzz to 22 000 new seeds: a shadow ray that leaves one half of a flat quad INSIDE the quad's plane (a light
+    flush with the wall).  Against a coplanar triangle Moeller-Trumbore's determinant is rounding noise (1.4e-6 where |e1||e2| = 2.8; exact
+    arithmetic says miss, fp32 said hit with u = v = 0.5), so with `det == 0` as the only degenerate case the ray counted as occluded exactly
+    when that triangle got TESTED: two-triangle leaf slots always test the partner (seeds 20341, 104187, 50035: HIP path = brute force != the
+    oracle's BVH).  The contract now calls |det| <= 1e-6 |e1|_1 |d x e2|_1 a miss (pt_bvh.h intersect_triangle, the oracle alike): the HIP path,
+    the oracle's BVH and the oracle's brute-force traversal agree again, bit for bit.
+    What no determinant rule removes (seed 310601): a ray 3e-6 off the plane of a triangle 0.1 units small, 5 units away — the determinant is
+    accurate, the barycentric numerator s . p is not (its terms are 50x the result), fp32 says u = -0 where exact arithmetic says -0.14.  Every
+    structure that tests that triangle reports the same false hit (one BVH, the oracle's tree, brute force); the two-level structure's tighter
+    object-space boxes do not reach it.  One pixel-sample in 1 500 two-level scenes; documented, not hidden: the assertion below allows it."""
+    sc = scenes.random_scene(seed, extras=extras)
+    w, h, B, spp, first, flags, space = 96, 54, 3 + seed % 7, 2 + seed % 2, 0, abi.FLAG_MULTISCATTER_GGX, scenes.BT2020
+    if seed % 3 == 0:
+        w, h = 71, 45
+    if extras:
+        flags = abi.FLAG_MULTISCATTER_GGX if seed % 5 else 0
+        space = scenes.BT2020 if seed % 7 else scenes.BT709
+        first, spp = (seed % 13) * 3, 2 + seed % 4
+    if seed % 6 == 5:
+        spp, (w, h) = 33 + seed % 41, ((40, 27) if seed % 3 else (33, 18))
+    integ = abi.INTEGRATOR_MIS if seed % 4 else abi.INTEGRATOR_SIMPLE
+    gpu_renderer.selectKernel(integ)
+    gpu_renderer.startRender(sc, (w, h), spp, workingSpace=space, flags=flags, max_bounces=B, first_sample=first,
+                             accel_structure=abi.ACCEL_TWO_LEVEL if two_level else abi.ACCEL_ONE_BVH)
     gpu_renderer.render(0)
     acc = gpu_renderer.readbackAccumulator()
-    brute = oracle_lib.OracleScene(sc, p, use_bvh=False).render(0, 3)
-    assert _same_bits_or_both_nan(acc, brute)
-    tree = oracle_lib.OracleScene(sc, p, use_bvh=True).render(0, 3)
-    differing = np.argwhere((acc.view(np.uint32) != tree.view(np.uint32)).any(-1))
-    assert len(differing) <= 1 and np.allclose(acc, tree, rtol=1e-5, atol=1e-7)   # (the stated tolerance of the contract holds either way)
+    gpu_renderer.selectKernel(abi.INTEGRATOR_MIS)
+    p = make_params(w, h, spp, B, flags=flags, integrator=integ, working_space=space, first_sample=first)
+    tree = oracle_lib.OracleScene(sc, p, use_bvh=True).render(first, spp)
+    brute = oracle_lib.OracleScene(sc, p, use_bvh=False).render(first, spp)
+    assert _same_bits_or_both_nan(tree, brute)
+    if two_level:
+        differing = np.argwhere((acc.view(np.uint32) != tree.view(np.uint32)).any(-1))
+        assert len(differing) <= 1 and np.nanmax(np.abs(acc - tree)) < 1e-5 and np.array_equal(np.isnan(acc), np.isnan(tree))
+    else:
+        assert _same_bits_or_both_nan(acc, tree)
 
 
 @pytest.mark.parametrize("seed", list(range(24)) + [1000 + i for i in range(12)])
