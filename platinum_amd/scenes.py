@@ -707,6 +707,38 @@ def atrium_scene(env_size=(4096, 2048), columns=20):
     return sc
 
 
+def pairing_edge_cases_scene():
+    """One INDEXED mesh whose consecutive triangles exercise every branch of the leaf-slot pairing (host_scene.h pair_mesh_triangles, lbvh.hip
+    k_flatten): a plain quad; a fan of three (the third stays single); a partner that repeats a vertex (zero area, still a pair); a degenerate
+    first triangle with a proper partner; a partner that shares all three indices (not a pair); triangles that share only one vertex; a
+    mirrored duplicate (same three indices in another order); two materials across one pair.  Two instances, one mirrored."""
+    import numpy as _np
+    P = _np.array([[-2, 0, -2], [-2, 0, 2], [2, 0, -2], [2, 0, 2],            # 0-3 floor quad
+                   [-3, 0.5, 0], [-2.5, 1.5, 0.3], [-2, 0.6, 0.5], [-1.5, 1.4, 0.2], [-1, 0.5, 0],   # 4-8 fan
+                   [0, 1, -1], [1, 1, -1], [0.5, 2, -1.2], [1.5, 2.1, -0.8],      # 9-12
+                   [3, 0.2, 1], [3.5, 1.2, 1], [4, 0.3, 1.2], [2.5, 1.0, 0.5]], dtype=_np.float32)
+    I = _np.array([0, 1, 2,  2, 1, 3,           # quad: pair
+                   4, 5, 6,  4, 6, 7,  4, 7, 8,  # fan: pair + single
+                   9, 10, 11,  9, 9, 12,         # partner repeats a vertex: shared = 2 (9, 9), pair with a zero-area B
+                   10, 10, 11,  10, 11, 12,      # degenerate A, proper B
+                   13, 14, 15,  15, 13, 14,      # the same triangle twice (shared = 3): not a pair; the tie-break decides
+                   13, 15, 16,  0, 16, 12,       # shares one vertex with its predecessor: single, single
+                   5, 6, 7,  7, 6, 5], dtype=_np.uint32)   # a mirrored duplicate (shared = 3)
+    n = _np.tile(_np.array([[0, 1, 0]], _np.float32), (len(P), 1))
+    tg = _np.tile(_np.array([[1, 0, 0, 1]], _np.float32), (len(P), 1))
+    uv = (P[:, [0, 2]] * 0.25).astype(_np.float32)
+    slots = _np.zeros(len(I) // 3, _np.uint32)
+    slots[1] = 1                                   # the quad's halves carry different materials (different shading classes in one slot)
+    sc = Scene(name="pairing")
+    m = sc.add_mesh(_make_mesh(P, n, tg, uv, I, slots))
+    mats = [Material(base_color=(0.7, 0.6, 0.5, 1.0), roughness=0.8), Material(base_color=(0.9, 0.9, 0.9, 1.0), roughness=0.2, metallic=1.0)]
+    sc.add_instance(m, Transform(translation=(0, 0, 0)), mats)
+    sc.add_instance(m, Transform(translation=(0.3, 2.5, -1.0), scale=(-0.8, 0.9, 1.1)), mats)
+    sc.env_texture = sc.add_texture(sky_environment(16, 8), 4)
+    sc.set_camera(Camera.with_focal_length(24.0), Transform(translation=(0.5, 3.5, 7), target=(0.3, 1, 0), track=True))
+    return sc
+
+
 CONFIGS = {
     # name: (scene factory, width, height, spp, bounces)
     "c1": (lambda: cornell_scene("bench"), 512, 512, 64, 4),

@@ -805,6 +805,27 @@ def test_leaf_slots_hold_two_triangles_and_the_one_triangle_form_gives_the_same_
     monkeypatch.delenv("PTAMD_NO_PAIRS", raising=False)
 
 
+@pytest.mark.parametrize("accel", [abi.ACCEL_ONE_BVH, abi.ACCEL_TWO_LEVEL])
+def test_leaf_slot_pairing_edge_cases(gpu_renderer, accel):
+    """scenes.pairing_edge_cases_scene on the device builder (host_scene.h pair_mesh_triangles -> lbvh.hip k_flatten): plain quad, fan of three, a
+    partner with a repeated vertex, a degenerate first triangle, duplicated triangles, triangles sharing one vertex, two materials (two shading
+    classes) inside one slot, a mirrored instance — hits, per-sample radiance and image against the oracle; the pairs actually form."""
+    sc = scenes.pairing_edge_cases_scene()
+    gpu_renderer.selectKernel(abi.INTEGRATOR_MIS)
+    gpu_renderer.startRender(sc, (128, 80), 3, max_bounces=5, accel_structure=accel)
+    st = gpu_renderer.stats()
+    assert st.triangles == 30 and st.leaf_slots == (20 if accel == abi.ACCEL_ONE_BVH else 30)   # 2 instances x (15 triangles -> 10 slots: 5 pairs + 5 singles)
+    p = make_params(128, 80, 3, 5)
+    o = oracle_lib.OracleScene(sc, p)
+    assert gpu_renderer.tracePrimary(1).tobytes() == o.trace_primary(1).tobytes()
+    for s in (0, 2):
+        rg, hg = gpu_renderer.debugSample(s)
+        rc, hc = o.debug_sample(s)
+        assert np.array_equal(hg, hc) and _same_bits_or_both_nan(rg, rc)
+    gpu_renderer.render(0)
+    assert _same_bits_or_both_nan(gpu_renderer.readbackAccumulator(), o.render(0, 3))
+
+
 @pytest.mark.parametrize("seed,extras,two_level", [(20341, False, False), (104187, False, False), (50035, True, False), (310601, True, False), (310601, True, True)])
 def test_rays_in_a_triangles_plane_miss_it_whatever_structure_is_walked(gpu_renderer, seed, extras, two_level):
     """r4, found by extending the fuzz to 22 000 new seeds: a shadow ray that leaves one half of a flat quad INSIDE the quad's plane (a light

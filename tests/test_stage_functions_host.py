@@ -109,6 +109,23 @@ def test_threaded_host_render_of_the_shared_kernels_equals_the_oracle(name, monk
     assert np.array_equal(e.render(0, 5, threads=1).view(np.uint32)[~nan], want.view(np.uint32)[~nan])
 
 
+def test_leaf_slot_pairing_edge_cases_on_the_host(monkeypatch):
+    """scenes.pairing_edge_cases_scene: every branch of the pairing (plain quad, fan, zero-area partner, degenerate first triangle, duplicates, one
+    shared vertex, two materials in one slot, a mirrored instance) through the product's traversal compiled for the host, against the oracle."""
+    for k, v in (("EMU_MORTON", "1"), ("EMU_PLOC", "8"), ("EMU_WIDE6", "1"), ("EMU_PAIRS", "1")):
+        monkeypatch.setenv(k, v)
+    sc = scenes.pairing_edge_cases_scene()
+    p = make_params(96, 64, 2, 5)
+    o, e = oracle_lib.OracleScene(sc, p), emu_lib.EmuScene(sc, p)
+    assert o.trace_primary(0).tobytes() == e.trace_primary(0).tobytes()
+    assert (o.trace_primary(0)["instance"] >= 0).mean() > 0.2
+    for s in (0, 1):
+        ro, ho = o.debug_sample(s)
+        re_, he = e.debug_sample(s)
+        nan = np.isnan(ro)
+        assert np.array_equal(ho, he) and np.array_equal(nan, np.isnan(re_)) and np.array_equal(ro.view(np.uint32)[~nan], re_.view(np.uint32)[~nan])
+
+
 def test_halton_fp32_division_boundaries_equal_oracle():
     """The strength-reduced radical inverse of pt_sampler.h at the multiples of every dimension's chunk (+-1), around 2^21 and at
     the top of the 32-bit range.  (An fp32 division of the small quotients was tried on top of it: bit-exact, but slower.)"""
