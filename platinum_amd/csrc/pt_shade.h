@@ -426,16 +426,18 @@ PT_HD ShadeOut stage_shade(const DeviceScene& S, const ShadeIn& in) {
   out.has_emitted = bo.has_emitted;
   out.shadow = nee.shadow;
   out.shadow_o = g.hitPos;
-  out.shadow_d = nee.d;
-  out.shadow_tmax = nee.tmax;
-  out.shadow_contrib = nee.contrib;
-  out.shadow_payload = nee.payload;
+  out.shadow_d = nee.shadow ? nee.d : v3(0.0f);
+  out.shadow_tmax = nee.shadow ? nee.tmax : 0.0f;
+  out.shadow_contrib = nee.shadow ? nee.contrib : v3(0.0f);
+  out.shadow_payload = nee.shadow ? nee.payload : 0.0f;
   out.alive = bo.alive;
   out.next_o = g.hitPos;
-  out.next_d = bo.next_d;
-  out.next_att = bo.next_att;
-  out.next_pdf = bo.next_pdf;
-  out.next_specular = bo.next_specular;
+  // (shade_bounce leaves the next-ray fields unwritten for a path that ends here, NEE likewise: the kernel never reads them then; this chain
+  //  must not copy indeterminate values either — UBSan on the host build, r4)
+  out.next_d = bo.alive ? bo.next_d : v3(0.0f);
+  out.next_att = bo.alive ? bo.next_att : v3(0.0f);
+  out.next_pdf = bo.alive ? bo.next_pdf : 0.0f;
+  out.next_specular = bo.alive ? bo.next_specular : false;
   out.dim = bo.dim;
   return out;
 }
