@@ -784,6 +784,7 @@ def test_leaf_slots_hold_two_triangles_and_the_one_triangle_form_gives_the_same_
     give the oracle's hits, per-sample radiance and image bit for bit — which triangles share a slot cannot change an answer."""
     if "PTAMD_NO_PAIRS" in os.environ:
         pytest.skip("$PTAMD_NO_PAIRS is preset for this session")
+    skip_if_structure_env_preset()
     for sc in (scenes.field_scene(6), scenes.random_scene(9), scenes.textured_scene()):
         w, h, B = 120, 68, 6
         o = None
@@ -814,7 +815,8 @@ def test_leaf_slot_pairing_edge_cases(gpu_renderer, accel):
     gpu_renderer.selectKernel(abi.INTEGRATOR_MIS)
     gpu_renderer.startRender(sc, (128, 80), 3, max_bounces=5, accel_structure=accel)
     st = gpu_renderer.stats()
-    assert st.triangles == 30 and st.leaf_slots == (20 if accel == abi.ACCEL_ONE_BVH else 30)   # 2 instances x (15 triangles -> 10 slots: 5 pairs + 5 singles)
+    if "PTAMD_NO_PAIRS" not in os.environ and "PTAMD_TWO_LEVEL" not in os.environ:   # (a preset switch changes the slot count, not the image)
+        assert st.triangles == 30 and st.leaf_slots == (20 if accel == abi.ACCEL_ONE_BVH else 30)   # 2 instances x (15 triangles -> 10 slots: 5 pairs + 5 singles)
     p = make_params(128, 80, 3, 5)
     o = oracle_lib.OracleScene(sc, p)
     assert gpu_renderer.tracePrimary(1).tobytes() == o.trace_primary(1).tobytes()
