@@ -125,32 +125,127 @@ def parse_args(argv=None):
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: a FIXED render of --spp samples per pixel split over the N GPUs (BASELINE.json configs[3], C4: "
                          "`--gpus 8 --strong --spp 1024` = 8 x 128, one reduce); --steps is derived = ceil(spp / N / spp-per-step); reports time to image")
+    ap.add_argument("--launch-timeout", type=float, default=0.0,
+                    help="N > 1 started without a launcher: seconds after which the parent ends the rank processes and reports their last lines "
+                         "(default %.0f)" % LAUNCH_TIMEOUT_S)
+    ap.add_argument("--rank-timeout", type=float, default=480.0,
+                    help="N > 1: seconds after which a rank that has not finished dumps its Python stacks to stderr and exits (no GPU call is made "
+                         "by the watchdog); 0 = off")
     ap.add_argument("--spp", type=int, default=0, help="--strong: total samples per pixel of the render (default: the workload's full spp, 1024 for c3 = C4)")
     return ap.parse_args(argv)
 
 
+LAUNCH_TIMEOUT_S = 420.0   # wall limit of a self-launched N-rank run: below the driver's 600 s, so that a stalled rendezvous is reported by
+                           # THIS process (each rank's last lines) instead of the whole job being killed "for writing nothing"
+
+
+def _rank_logs(log_dir):
+    """{(local_rank, 'stdout'|'stderr'): path} of the per-rank files torch.distributed.run --redirects 3 writes under --log-dir."""
+    out = {}
+    for root, _dirs, files in os.walk(log_dir):
+        for f in files:
+            if f in ("stdout.log", "stderr.log"):
+                try:
+                    out[(int(os.path.basename(root)), f[:-4])] = os.path.join(root, f)
+                except ValueError:
+                    pass
+    return out
+
+
+def _tail(path, n=25):
+    try:
+        with open(path, "r", errors="replace") as fh:
+            return fh.read().splitlines()[-n:]
+    except OSError:
+        return []
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start N ranks as fresh child processes.  Nothing in THIS process has
-    imported torch or touched the GPU (a process that has initialised the GPU must never exec or fork GPU work)."""
+    imported torch or touched the GPU (a process that has initialised the GPU must never exec or fork GPU work), so it is the one
+    that may watch the clock: after --launch-timeout seconds it ends the child process GROUP, prints what every rank last wrote and
+    exits 124.  Ranks are never restarted (--max-restarts 0): a rank that has touched the GPU is only ever replaced by a fresh run."""
+    import signal
     import socket
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    log_dir = tempfile.mkdtemp(prefix="ptamd_bench_ranks_")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), "--max-restarts", "0", "--log-dir", log_dir, "--redirects", "3",
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    env.setdefault("NCCL_DEBUG", "WARN")
+    limit = args.launch_timeout if args.launch_timeout > 0 else LAUNCH_TIMEOUT_S
+    t0 = time.monotonic()
+    print("bench.py[launcher pid %d]: starting %d ranks (limit %.0f s, per-rank logs under %s)" % (os.getpid(), args.gpus, limit, log_dir),
+          file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    print("bench.py[launcher]: ranks run in process group %d" % child.pid, file=sys.stderr, flush=True)
+    timed_out = False
+    last_note = t0
+    while True:
+        try:
+            child.wait(timeout=2.0)
+            break
+        except subprocess.TimeoutExpired:
+            pass
+        now = time.monotonic()
+        if now - last_note >= 30.0:   # a heartbeat: a long multi-rank run is not mistaken for a hung one
+            last_note = now
+            logs = _rank_logs(log_dir)
+            up = sum(1 for (r, k), pth in logs.items() if k == "stderr" and any("process group up" in ln for ln in _tail(pth, 200)))
+            print("bench.py[launcher]: %.0f s, %d/%d ranks have a process group" % (now - t0, up, args.gpus), file=sys.stderr, flush=True)
+        if now - t0 > limit:
+            timed_out = True
+            for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+                try:
+                    os.killpg(child.pid, sig)      # the launcher AND its ranks (own session = own process group)
+                except ProcessLookupError:
+                    break
+                try:
+                    child.wait(timeout=grace)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+            break
+    try:
+        l_out, l_err = child.communicate(timeout=5.0)
+    except subprocess.TimeoutExpired:
+        l_out, l_err = "", ""
+    logs = _rank_logs(log_dir)
     line = None
-    for ln in p.stdout.splitlines():
+    for ln in _tail(logs.get((0, "stdout"), ""), 1000) + (l_out or "").splitlines():
+        ln = ln.split("]:", 1)[-1].strip() if ln.startswith("[") else ln
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
-    if line is not None:
+    rc = 124 if timed_out else child.returncode
+    ok = line is not None and rc == 0
+    if ok:
         print(line)
-    else:
-        sys.stdout.write(p.stdout)
-    return p.returncode if line is not None or p.returncode != 0 else 1
+    # every rank's start-up lines on success; every rank's last lines when anything went wrong
+    for r in range(args.gpus):
+        err = _tail(logs.get((r, "stderr"), ""), 200)
+        if ok:
+            err = [ln for ln in err if ln.startswith("bench.py[rank")]
+        else:
+            err = err[-25:]
+        for ln in err:
+            print("[rank %d] %s" % (r, ln), file=sys.stderr)
+        if not ok and not err:
+            print("[rank %d] (wrote nothing to stderr%s)" % (r, "" if (r, "stderr") in logs else ": never started"), file=sys.stderr)
+    if not ok:
+        for ln in (l_err or "").splitlines()[-15:]:
+            print("[launcher] " + ln, file=sys.stderr)
+        print("bench.py[launcher]: %s after %.0f s; no result line" % ("TIMEOUT: child process group ended" if timed_out else "ranks exited with code %s" % rc,
+              time.monotonic() - t0), file=sys.stderr, flush=True)
+        return rc if rc not in (0, None) else 1
+    import shutil
+    shutil.rmtree(log_dir, ignore_errors=True)
+    return 0
 
 
 def load_pmc_profile(workload):
@@ -239,12 +334,28 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.inproc:
         sys.exit(self_launch(args))
 
-    import numpy as np  # noqa: F401
-    import torch
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    def say(msg):
+        print("bench.py[rank %d/%d pid %d] %s" % (rank, world, os.getpid(), msg), file=sys.stderr, flush=True)
+
+    if world > 1:
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        say("started: LOCAL_RANK %s, device ordinal %d, MASTER %s:%s" % (os.environ.get("LOCAL_RANK"), 0 if args.rehearse_on_device0 else local_rank,
+            os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")))
+        if args.rank_timeout > 0:
+            # a stalled rendezvous / collective: this rank reports where it stands and exits by itself (the watchdog thread only writes
+            # and calls _exit: it never touches the GPU, and the rank is not restarted)
+            import faulthandler
+            faulthandler.dump_traceback_later(args.rank_timeout, exit=True, file=sys.stderr)
+        if os.environ.get("PTAMD_BENCH_TEST_STALL"):   # tests/test_multi_gpu_gloo.py: a rank that never comes back
+            time.sleep(1e6)
+
+    import numpy as np  # noqa: F401
+    import torch
+
     inproc = args.inproc and args.gpus > 1
     if inproc and world != 1:
         raise SystemExit("--inproc drives all devices from one process: do not start it under torch.distributed.run")
@@ -254,13 +365,24 @@ def main():
     if args.rehearse_on_device0:
         local_rank = 0
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
+        t_pg = time.perf_counter()
         if args.rehearse_on_device0:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=180))
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+            if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+                say("no HIP device %d (torch sees %d): this rank cannot run" % (local_rank, torch.cuda.device_count() if torch.cuda.is_available() else 0))
+                raise SystemExit(3)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),  # nccl == RCCL on ROCm
+                                    timeout=datetime.timedelta(seconds=180))
+        say("process group up: backend %s, %.1f s" % (dist.get_backend(), time.perf_counter() - t_pg))
+    if not torch.cuda.is_available():
+        if world > 1:
+            say("no HIP device: this rank cannot render (rendezvous was fine)")
+        raise SystemExit("bench.py needs a HIP device" if world == 1 else 3)
 
     from platinum_amd import Renderer, abi, scenes
     from platinum_amd.sharding import reduce_accumulator, shard_samples
@@ -307,6 +429,10 @@ def main():
     n_gpus = len(set(devices)) if inproc else (1 if args.rehearse_on_device0 else world)
     rehearsal = n_gpus != members_all
     r = Renderer(devices=devices) if inproc else Renderer(device=local_rank)
+    if world > 1:
+        ri = abi.runtime_info()
+        say("renderer on device %d; HIP runtime %s (%d mapped), RCCL %s" % (local_rank, ri["hip_runtime_path"], ri["hip_runtimes_mapped"],
+            ri["rccl_path"] or "(torch's, bound by torch.distributed)"))
     # samples of this process: K*S per device, timed; the warm-up renders (and discards) W*S of the same range first
     total_spp = K * S * ndev
     if args.strong:
@@ -487,7 +613,14 @@ def main():
             dt = time.perf_counter() - t0
             return n, dt, W * H * n * B / dt / 1e6, float(a[..., :3].mean())
 
-        os.environ.update(EMU_MORTON="1", EMU_PLOC="8", EMU_WIDE6="1")  # the product's tree: Morton order, PLOC radius 8, SAH collapse to 6-wide nodes
+        # the product's tree: Morton order, PLOC radius 8, SAH collapse to 6-wide nodes, leaf slots of one or two triangles (unless the
+        # library itself runs with $PTAMD_NO_PAIRS)
+        os.environ.update(EMU_MORTON="1", EMU_PLOC="8", EMU_WIDE6="1")
+        pairs = "PTAMD_NO_PAIRS" not in os.environ
+        if pairs:
+            os.environ["EMU_PAIRS"] = "1"
+        else:
+            os.environ.pop("EMU_PAIRS", None)
         t0 = time.perf_counter()
         e = emu_lib.EmuScene(scene, make_params(W, H, 64, B))
         host_build_s = time.perf_counter() - t0
@@ -498,8 +631,8 @@ def main():
         out["cpu_baseline"] = {
             "value": round(v_e, 3), "unit": "Msamples/s", "cores": threads, "kind": "same-kernels-host", "cpu_model": cpu_model,
             "sample": "%dx%d x %d spp x %d bounces (sample indices 1..%d) of the same scene: the product's stage functions and 6-wide BVH traversal "
-                      "compiled for the host (tests/emu), std::thread over 16x16 tiles, %.1f s; host BVH build %.1f s not included"
-                      % (W, H, n_e, B, n_e, dt_e, host_build_s),
+                      "(%s leaf slots) compiled for the host (tests/emu), std::thread over 16x16 tiles, %.1f s; host BVH build %.1f s not included"
+                      % (W, H, n_e, B, n_e, "pair" if pairs else "one-triangle", dt_e, host_build_s),
             "mean_radiance": mean_e,
             "gpu_over_cpu": round(value / v_e, 1),
             "oracle": {"value": round(v_o, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
@@ -507,10 +640,14 @@ def main():
         }
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     r.close()
     if dist is not None:
+        say("done: %.1f ms timed" % (elapsed * 1e3))
         dist.destroy_process_group()
+        if args.rank_timeout > 0:
+            import faulthandler
+            faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":

@@ -1621,6 +1621,41 @@ int orc_debug_sample(orc_scene* sc, uint32_t sample_idx, float* radiance_out, in
   return 0;
 }
 
+// A list of pixels through the very loop of orc_render: samples [first_sample, first_sample + nsamples) of pixel (xy[2i], xy[2i+1]) folded
+// into out[4i..4i+3] with the running-mean rule of kernel.metal:672-684 (acc_n0 samples already in it; no GMoN).  What the full-size
+// parity tests compare the HIP accumulator with at BASELINE.json's sizes, where a whole oracle frame would take minutes.
+int orc_render_pixels(orc_scene* sc, const uint32_t* xy, uint32_t npixels, uint32_t first_sample, uint32_t nsamples, float* out,
+                      uint32_t acc_n0, int threads) {
+  if (threads < 1) threads = 1;
+  std::atomic<uint32_t> next{0};
+  auto worker = [&]() {
+    ThreadStats st;
+    for (;;) {
+      const uint32_t i = next.fetch_add(1);
+      if (i >= npixels) break;
+      float* px = &out[4 * (size_t)i];
+      for (uint32_t s = 0; s < nsamples; s++) {
+        float3 L = trace_path(*sc, xy[2 * i], xy[2 * i + 1], first_sample + s, nullptr, st, false);
+        if (!(fabsf(L.x) <= 3.0e38f && fabsf(L.y) <= 3.0e38f && fabsf(L.z) <= 3.0e38f)) {
+          if (sc->params.nonfinite_policy == PT_NONFINITE_ZERO) L = f3(0.0f);
+        }
+        const uint32_t f = acc_n0 + s;
+        if (f > 0) {
+          float3 L_prev = f3(px[0], px[1], px[2]);
+          L += L_prev * (float)f;
+          L /= (float)(f + 1);
+        }
+        px[0] = L.x; px[1] = L.y; px[2] = L.z; px[3] = 1.0f;
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+  worker();
+  for (auto& t : pool) t.join();
+  return 0;
+}
+
 // Verbose single-path trace to stderr (debugging aid).
 int orc_debug_pixel(orc_scene* sc, uint32_t x, uint32_t y, uint32_t sample_idx, float* L_out) {
   ThreadStats st;

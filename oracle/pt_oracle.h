@@ -32,6 +32,8 @@ int orc_postprocess(const orc_scene* sc, const float* acc, const pt_post_options
 int orc_trace_primary(orc_scene* sc, uint32_t sample_idx, pt_hit_record* out);
 int orc_debug_sample(orc_scene* sc, uint32_t sample_idx, float* radiance_out, int32_t* hits_out, int threads);
 int orc_debug_pixel(orc_scene* sc, uint32_t x, uint32_t y, uint32_t sample_idx, float* L_out);
+int orc_render_pixels(orc_scene* sc, const uint32_t* xy, uint32_t npixels, uint32_t first_sample, uint32_t nsamples, float* out,
+                      uint32_t acc_n0, int threads);
 int orc_get_stats(const orc_scene* sc, orc_stats* out);
 
 uint32_t orc_halton_offset(uint32_t x, uint32_t y, uint32_t sample);

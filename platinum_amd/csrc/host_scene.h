@@ -29,6 +29,7 @@ struct HostScene {
   std::vector<uint8_t> tex_data;         // every texture in its own format, each at a multiple of 16 bytes (pt_device.h TexInfo)
   std::vector<float> tex_decode;         // unorm[256], srgb[256]: the floats 8-bit texels decode to
   std::vector<TexInfo> textures;
+  uint32_t tex_native = 0;               // some texture is stored in an 8-bit form (DeviceScene::tex_native)
   std::vector<pt_alias_entry> env_alias;
   int32_t env_texture = -1;
   bool has_alpha = false;
@@ -212,6 +213,7 @@ inline int decode_textures(const pt_scene_snapshot* scene, HostScene* out, std::
     base = (base + 15u) / 16u * 16u;
     if (native || tx.format == PT_TEX_RGBA32F) {
       out->textures[t] = {(uint32_t)(base / 16u), tx.width, tx.height, tx.format};
+      if (tx.format != PT_TEX_RGBA32F) out->tex_native = 1;
       memcpy(&out->tex_data[base], tx.pixels, n * tex_bytes_per_texel(tx.format));
       base += n * tex_bytes_per_texel(tx.format);
     } else {  // decoded once, through the same tables a fetch of the 8-bit form goes through

@@ -78,6 +78,17 @@ PT_HD vec4 tex_fetch(const DeviceScene& S, const TexInfo& t, size_t i) {
   }
   return vec4{ldg(&unorm[ldg(base + i)]), 0.0f, 0.0f, 1.0f};  // PT_TEX_R8
 }
+// The storage form is a property of the SCENE (host_scene.h decode_textures): when no texture kept an 8-bit form (S.tex_native == 0, a
+// wave-uniform scalar) every texel is a float4 and the four taps are four plain loads — the format chain of tex_fetch is not even
+// entered.  r4 ran that chain inside each tap of every sample (C5 k_shade +8.5 %).
+PT_HD vec4 tex_bilerp(const vec4& p00, const vec4& p01, const vec4& p10, const vec4& p11, float wx, float wy) {
+  vec4 o;
+  { const float a = p00.x + (p01.x - p00.x) * wx, b = p10.x + (p11.x - p10.x) * wx; o.x = a + (b - a) * wy; }
+  { const float a = p00.y + (p01.y - p00.y) * wx, b = p10.y + (p11.y - p10.y) * wx; o.y = a + (b - a) * wy; }
+  { const float a = p00.z + (p01.z - p00.z) * wx, b = p10.z + (p11.z - p10.z) * wx; o.z = a + (b - a) * wy; }
+  { const float a = p00.w + (p01.w - p00.w) * wx, b = p10.w + (p11.w - p10.w) * wx; o.w = a + (b - a) * wy; }
+  return o;
+}
 PT_HD vec4 tex_sample(const DeviceScene& S, int id, vec2 uv) {
   const TexInfo t = ldg(&S.textures[id]);
   const float fx = uv.x * (float)t.w - 0.5f, fy = uv.y * (float)t.h - 0.5f;
@@ -85,14 +96,14 @@ PT_HD vec4 tex_sample(const DeviceScene& S, int id, vec2 uv) {
   const float wx = fx - x0f, wy = fy - y0f;
   const int x0 = tex_wrap((int)x0f, (int)t.w), x1 = tex_wrap((int)x0f + 1, (int)t.w);
   const int y0 = tex_wrap((int)y0f, (int)t.h), y1 = tex_wrap((int)y0f + 1, (int)t.h);
-  const vec4 p00 = tex_fetch(S, t, (size_t)y0 * t.w + x0), p01 = tex_fetch(S, t, (size_t)y0 * t.w + x1);
-  const vec4 p10 = tex_fetch(S, t, (size_t)y1 * t.w + x0), p11 = tex_fetch(S, t, (size_t)y1 * t.w + x1);
-  vec4 o;
-  { const float a = p00.x + (p01.x - p00.x) * wx, b = p10.x + (p11.x - p10.x) * wx; o.x = a + (b - a) * wy; }
-  { const float a = p00.y + (p01.y - p00.y) * wx, b = p10.y + (p11.y - p10.y) * wx; o.y = a + (b - a) * wy; }
-  { const float a = p00.z + (p01.z - p00.z) * wx, b = p10.z + (p11.z - p10.z) * wx; o.z = a + (b - a) * wy; }
-  { const float a = p00.w + (p01.w - p00.w) * wx, b = p10.w + (p11.w - p10.w) * wx; o.w = a + (b - a) * wy; }
-  return o;
+  const size_t i00 = (size_t)y0 * t.w + x0, i01 = (size_t)y0 * t.w + x1, i10 = (size_t)y1 * t.w + x0, i11 = (size_t)y1 * t.w + x1;
+  if (!S.tex_native) {
+    const vec4* texels = reinterpret_cast<const vec4*>(S.tex_data + (size_t)t.offset16 * 16u);
+    const vec4 p00 = ldg(texels + i00), p01 = ldg(texels + i01), p10 = ldg(texels + i10), p11 = ldg(texels + i11);
+    return tex_bilerp(p00, p01, p10, p11, wx, wy);
+  }
+  const vec4 p00 = tex_fetch(S, t, i00), p01 = tex_fetch(S, t, i01), p10 = tex_fetch(S, t, i10), p11 = tex_fetch(S, t, i11);
+  return tex_bilerp(p00, p01, p10, p11, wx, wy);
 }
 
 PT_HD ShadingContext make_shading_context(const DeviceScene& S, const pt_material_gpu& mat, vec2 uv) {

@@ -216,6 +216,7 @@ struct DeviceScene {
   const uint8_t* tex_data;          // every texture in its own format, each starting at a multiple of 16 bytes
   const float* tex_decode;          // kTexDecodeEntries floats: unorm[256], srgb[256]
   const TexInfo* textures;
+  uint32_t tex_native;              // some texture kept an 8-bit form: taps decode per format (0: every texel is a float4)
   const pt_alias_entry* env_alias;  // EnvironmentLight::alias (pt_shader_defs.hpp:70-73)
   int32_t env_texture;              // -1: no environment light
   uint32_t envLightCount;           // 0 or 1

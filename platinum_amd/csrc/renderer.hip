@@ -334,7 +334,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   S.camera = C.camera;
   S.idt = idt;
   S.width = p->width; S.height = p->height;
-  S.tex_data = r->tex_data.p; S.tex_decode = r->tex_decode.p; S.textures = r->textures.p; S.env_alias = r->env_alias_d.p;
+  S.tex_data = r->tex_data.p; S.tex_decode = r->tex_decode.p; S.textures = r->textures.p; S.tex_native = hs.tex_native; S.env_alias = r->env_alias_d.p;
   S.env_texture = hs.env_texture;
   S.envLightCount = C.envLightCount;
   S.has_alpha = hs.has_alpha ? 1u : 0u;

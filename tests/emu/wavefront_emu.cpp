@@ -519,7 +519,7 @@ void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const
   S.camera = e->hs.constants.camera; S.idt = e->hs.idt; S.width = p->width; S.height = p->height;
   S.lightCount = e->hs.constants.lightCount; S.totalLightPower = e->hs.constants.totalLightPower;
   S.flags = p->flags; S.integrator = p->integrator; S.max_bounces = p->max_bounces;
-  S.tex_data = e->hs.tex_data.data(); S.tex_decode = e->hs.tex_decode.data(); S.textures = e->hs.textures.data(); S.env_alias = e->hs.env_alias.data();
+  S.tex_data = e->hs.tex_data.data(); S.tex_decode = e->hs.tex_decode.data(); S.textures = e->hs.textures.data(); S.tex_native = e->hs.tex_native; S.env_alias = e->hs.env_alias.data();
   S.env_texture = e->hs.env_texture; S.envLightCount = e->hs.constants.envLightCount; S.has_alpha = e->hs.has_alpha ? 1u : 0u;
   return e;
 }

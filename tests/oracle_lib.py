@@ -28,6 +28,22 @@ class OrcStats(C.Structure):
 _lib = None
 
 
+def host_threads():
+    """Worker threads for the oracle: the affinity mask cut down to the cgroup's CPU quota (a one-GPU box of the pool shows 256 logical
+    CPUs and grants 16; 256 threads on 16 cores run the oracle at half its speed)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(round(int(q) / int(per)))))
+    except (OSError, ValueError, IndexError):
+        pass
+    return max(1, n)
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "all"])
 
@@ -56,6 +72,7 @@ def lib():
     L.orc_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.PostOptions), C.POINTER(abi.TonemapOptions), C.c_void_p, C.c_void_p]
     L.orc_trace_primary.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     L.orc_debug_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_render_pixels.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int]
     L.orc_get_stats.argtypes = [C.c_void_p, C.POINTER(OrcStats)]
     L.orc_halton_offset.restype = C.c_uint32
     L.orc_halton_offset.argtypes = [C.c_uint32] * 3
@@ -143,15 +160,22 @@ class OracleScene:
     def render(self, first_sample, nsamples, acc=None, acc_n0=0, threads=None, count_traversal=False):
         if acc is None:
             acc = np.zeros((self.H, self.W, 4), dtype=np.float32)
-        threads = threads or os.cpu_count() or 1
+        threads = threads or host_threads()
         self.L.orc_render(self.h, first_sample, nsamples, acc.ctypes.data, acc_n0, threads, int(count_traversal))
         return acc
+
+    def render_pixels(self, xy, first_sample, nsamples, acc_n0=0, threads=None):
+        """The running mean of samples [first_sample, first_sample + nsamples) for the listed (x, y) pixels only: [len(xy), 4]."""
+        xy = np.ascontiguousarray(xy, dtype=np.uint32).reshape(-1, 2)
+        out = np.zeros((len(xy), 4), dtype=np.float32)
+        self.L.orc_render_pixels(self.h, xy.ctypes.data, len(xy), first_sample, nsamples, out.ctypes.data, acc_n0, threads or host_threads())
+        return out
 
     def render_gmon(self, nsamples, threads=None):
         """All `nsamples` (= params.spp) samples into the GMoN buckets; returns (buckets[B,H,W,4], resolved[H,W,4])."""
         B = self.params.gmon_buckets
         buckets = np.zeros((B, self.H, self.W, 4), dtype=np.float32)
-        self.L.orc_render(self.h, 0, nsamples, buckets.ctypes.data, 0, threads or os.cpu_count() or 1, 0)
+        self.L.orc_render(self.h, 0, nsamples, buckets.ctypes.data, 0, threads or host_threads(), 0)
         spb = (self.params.spp + B - 1) // B
         full = (nsamples - 1) // spb + 1
         return buckets, self.gmon_resolve(buckets, full)
@@ -178,7 +202,7 @@ class OracleScene:
         B = self.params.max_bounces
         rad = np.zeros((self.H, self.W, 4), dtype=np.float32)
         hits = np.zeros((B, self.H, self.W, 2), dtype=np.int32)
-        self.L.orc_debug_sample(self.h, sample_idx, rad.ctypes.data, hits.ctypes.data, threads or os.cpu_count() or 1)
+        self.L.orc_debug_sample(self.h, sample_idx, rad.ctypes.data, hits.ctypes.data, threads or host_threads())
         return rad, hits
 
     def stats(self):

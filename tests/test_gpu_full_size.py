@@ -1,0 +1,137 @@
+"""The configurations `bench.py` TIMES, compared with the oracle at their full size.
+
+`python bench.py` renders C3 at 1920x1080 with the batch the library plans for the image (128 samples in flight on an empty MI355X:
+32 400 segments, four bands, ~53 GB of queues); `--workload c2` the same for C2, `--workload c5` the ingested atrium at 3840x2160 with
+12 bounces.  A whole oracle frame of those sizes takes minutes, so each test here
+  * renders exactly what one bench step renders (same scene object, same size, same bounces, samples_in_flight = 0 -> the library's own
+    plan, the DEFAULT non-finite policy), reads the accumulator through the C ABI and compares ~1 000 pixels — image corners, both sides
+    of 8x8 tile borders, both sides of every segment-band border, object silhouettes found in the primary-hit ids, and a seeded random
+    set — with the oracle's running mean over the same samples (`orc_render_pixels`: the loop of `orc_render` for a list of pixels),
+    BIT FOR BIT (kernel.metal:672-684);
+  * compares the ray / shadow-ray / shaded-hit counters of a full-size two-sample render with the oracle's whole-frame counters;
+  * requires the whole 128-in-flight image to equal, bit for bit, the image the same library produces in batches of 16 (different segment
+    fill, different chunk tables, different accumulate folds — the same samples in the same order).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from platinum_amd import abi, scenes
+from platinum_amd.renderer import make_params
+
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_bits_or_both_nan(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
+
+
+def _probe_pixels(W, H, ids, n_random=512, seed=5):
+    """Pixels where a wavefront bug would show first.  `ids` = primary-hit instance ids [H, W] (silhouettes)."""
+    px = {(0, 0), (W - 1, 0), (0, H - 1), (W - 1, H - 1), (W // 2, H // 2)}
+    rng = np.random.default_rng(seed)
+    tx_n, ty_n = (W + 7) // 8, (H + 7) // 8
+    # both sides of tile borders (a tile = one wave of k_raygen, one segment's share of the queues)
+    for _ in range(48):
+        tx, ty = int(rng.integers(1, tx_n)), int(rng.integers(1, ty_n))
+        for dx in (-1, 0):
+            for dy in (-1, 0):
+                px.add((min(W - 1, 8 * tx + dx), min(H - 1, 8 * ty + dy)))
+    # both sides of the segment-band borders (kernels.hip seg_first_tile: the tile list is cut into 4 contiguous bands)
+    ntiles = tx_n * ty_n
+    for k in range(1, 4):
+        for t in (k * ntiles // 4 - 1, k * ntiles // 4):
+            tx, ty = t % tx_n, t // tx_n
+            for d in (0, 7):
+                px.add((min(W - 1, 8 * tx + d), min(H - 1, 8 * ty + d)))
+    # the last (partial) tile row / column
+    px.update({(W - 1, H // 3), (W // 3, H - 1), (8 * (tx_n - 1), 8 * (ty_n - 1))})
+    # silhouettes: pixels whose right or lower neighbour sees another instance
+    edge = np.zeros(ids.shape, bool)
+    edge[:, :-1] |= ids[:, :-1] != ids[:, 1:]
+    edge[:-1, :] |= ids[:-1, :] != ids[1:, :]
+    ey, ex = np.nonzero(edge)
+    if len(ex):
+        for i in rng.choice(len(ex), size=min(256, len(ex)), replace=False):
+            px.add((int(ex[i]), int(ey[i])))
+    for _ in range(n_random):
+        px.add((int(rng.integers(0, W)), int(rng.integers(0, H))))
+    return np.array(sorted(px), dtype=np.uint32)
+
+
+def _full_size_case(r, scene, W, H, B, spp_expected=None, counters_spp=2):
+    t_start = time.perf_counter()
+    r.selectKernel(abi.INTEGRATOR_MIS)
+    lib = abi.load_library()
+    import ctypes as C
+    import torch
+    free_b, _ = torch.cuda.mem_get_info(0)
+    plan = abi.QueuePlan()
+    abi.check(lib, lib.pt_plan_queues(W, H, 1 << 20, 0, int(free_b), 0, 4, C.byref(plan)))
+    S = int(plan.samples_in_flight)            # what bench.py calls spp_per_step
+    if spp_expected is not None and free_b > 200 << 30:
+        assert S == spp_expected, (S, spp_expected)
+    o = oracle_lib.OracleScene(scene, make_params(W, H, S, B))
+    # ---- counters of a full-size render of `counters_spp` samples against the oracle's whole frame ------------------------------------
+    r.startRender(scene, (W, H), counters_spp, max_bounces=B)
+    ids = r.tracePrimary(0)["instance"]
+    r.render(0)
+    r.wait()
+    st2 = r.stats()
+    o.render(0, counters_spp)
+    so = o.stats()
+    assert (st2.paths, st2.closest_rays, st2.shadow_rays, st2.shaded_hits) == (so.paths, so.closest_rays, so.shadow_rays, so.shaded_hits)
+    # ---- one bench step: the library's own batch for this image ----------------------------------------------------------------------
+    r.startRender(scene, (W, H), S, max_bounces=B)     # samples_in_flight = 0: the library plans; non-finite policy = the default (propagate)
+    assert r.stats().samples_in_flight == S
+    r.render(S)
+    r.wait()
+    st = r.stats()
+    assert st.batches == 1 and st.paths == W * H * S
+    acc = r.readbackAccumulator()
+    xy = _probe_pixels(W, H, ids)
+    ref = o.render_pixels(xy, 0, S)
+    o.close()
+    got = acc[xy[:, 1], xy[:, 0]]
+    bad = ~((got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))).all(axis=1)
+    assert not bad.any(), "pixels %s: HIP %s oracle %s" % (xy[bad][:4].tolist(), got[bad][:4].tolist(), ref[bad][:4].tolist())
+    assert (acc[..., 3] == 1).all() and np.nanmean(acc[..., :3]) > 1e-3
+    # ---- the same samples in batches of 16: the whole image, bit for bit --------------------------------------------------------------
+    r.startRender(scene, (W, H), S, max_bounces=B, samples_in_flight=16)
+    r.render(0)
+    r.wait()
+    assert r.stats().batches == -(-S // 16)
+    assert _same_bits_or_both_nan(r.readbackAccumulator(), acc)
+    return S, len(xy), time.perf_counter() - t_start
+
+
+def test_c3_as_the_driver_times_it_equals_the_oracle(gpu_renderer):
+    """BASELINE.json configs[2] — `python bench.py`: 1.04 M-triangle field, 1920x1080, 8 bounces, 128 samples in flight."""
+    factory, W, H, _spp, B = scenes.CONFIGS["c3"]
+    S, n, dt = _full_size_case(gpu_renderer, factory(), W, H, B, spp_expected=128)
+    print("C3 full size: %d samples in flight, %d probe pixels bit-identical, %.1f s" % (S, n, dt))
+
+
+def test_c2_as_the_driver_times_it_equals_the_oracle(gpu_renderer):
+    """BASELINE.json configs[1] — `python bench.py --workload c2`: Cornell box + GGX dielectric sphere, 1920x1080, 8 bounces."""
+    factory, W, H, _spp, B = scenes.CONFIGS["c2"]
+    S, n, dt = _full_size_case(gpu_renderer, factory(), W, H, B, spp_expected=128)
+    print("C2 full size: %d samples in flight, %d probe pixels bit-identical, %.1f s" % (S, n, dt))
+
+
+def test_c5_as_the_driver_times_it_equals_the_oracle(gpu_renderer, tmp_path):
+    """BASELINE.json configs[4] on one GPU — `python bench.py --workload c5`: the atrium written as .glb + .exr, read back by the
+    product's loaders, 3840x2160, 12 bounces, the planned batch (46 samples in flight on an empty MI355X)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import export_gltf
+    _factory, W, H, _spp, B = scenes.CONFIGS["c5"]
+    sc = export_gltf.atrium_through_ingestion(str(tmp_path))
+    S, n, dt = _full_size_case(gpu_renderer, sc, W, H, B, counters_spp=1)
+    assert S >= 32
+    print("C5 full size: %d samples in flight, %d probe pixels bit-identical, %.1f s" % (S, n, dt))

@@ -48,3 +48,54 @@ def test_two_rank_sample_sharding_equals_single_render(tmp_path):
     full = oracle_lib.OracleScene(scenes.cornell_sphere_scene(), make_params(W, H, 2 * SPP_PER_RANK, B)).render(0, 2 * SPP_PER_RANK)
     assert np.array_equal(merged[..., 3], np.ones((H, W), np.float32))
     np.testing.assert_allclose(merged[..., :3], full[..., :3], rtol=2e-6, atol=1e-6)
+
+
+# ---- the launcher of `python bench.py --gpus N` itself: it must not be able to die silently --------------------------
+def _bench(*argv, env=None, timeout=240):
+    import subprocess
+    e = dict(os.environ)
+    e.update(env or {})
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, timeout=timeout)
+
+
+def test_self_launch_of_a_stalled_job_times_out_and_reports_every_rank():
+    """Both ranks print their start-up line and then never come back (what a stalled RCCL rendezvous looks like from outside): the parent —
+    which never touched the GPU — ends the child process group at its wall limit, prints each rank's last lines and exits 124."""
+    import time
+    t0 = time.time()
+    p = _bench("--gpus", "2", "--launch-timeout", "12", "--no-cpu-baseline", env={"PTAMD_BENCH_TEST_STALL": "1"})
+    assert p.returncode == 124, (p.returncode, p.stderr[-2000:])
+    assert time.time() - t0 < 90
+    assert "TIMEOUT" in p.stderr and '"metric"' not in p.stdout
+    for r in (0, 1):
+        assert "[rank %d] bench.py[rank %d/2" % (r, r) in p.stderr and "started: LOCAL_RANK %d" % r in p.stderr, p.stderr[-2000:]
+    # nothing of the job is left behind
+    import re
+    pgid = int(re.search(r"ranks run in process group (\d+)", p.stderr).group(1))
+    with pytest.raises(ProcessLookupError):
+        os.killpg(pgid, 0)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the refusal path of a box WITHOUT a GPU")
+def test_self_launch_rendezvous_works_and_ranks_refuse_without_a_gpu():
+    """On this CPU-only box the launcher path runs as far as it can: two fresh ranks, a process group (gloo in the rehearsal form the
+    one-GPU box uses), then every rank finds no HIP device, says so and exits 3; the parent relays the lines and fails loudly."""
+    p = _bench("--gpus", "2", "--rehearse-on-device0", "--launch-timeout", "120", "--no-cpu-baseline")
+    assert p.returncode not in (0, 124), (p.returncode, p.stderr[-2000:])
+    assert '"metric"' not in p.stdout
+    for r in (0, 1):
+        assert "bench.py[rank %d/2" % r in p.stderr
+    assert p.stderr.count("process group up: backend gloo") == 2, p.stderr[-3000:]
+    assert "no HIP device" in p.stderr and "no result line" in p.stderr
+
+
+def test_a_rank_watchdog_ends_a_stalled_rank_with_its_stack():
+    """Under the DRIVER's own launcher there is no parent of ours: a rank that stalls dumps its Python stacks and exits by itself."""
+    import subprocess
+    e = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999", PTAMD_BENCH_TEST_STALL="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rank-timeout", "3"], env=e, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=60)
+    assert p.returncode != 0
+    assert "started: LOCAL_RANK 0" in p.stderr and "Timeout (0:00:03)!" in p.stderr and "bench.py" in p.stderr
