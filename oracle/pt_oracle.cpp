@@ -781,9 +781,13 @@ void build_bvh(orc_scene& sc) {
   if (n) build_node(sc, cent, 0, (uint32_t)n);
 }
 
+// r5: boxes are culled against tbest * (1 + 1e-4) (r1-r4: tbest) — fp32 Moeller-Trumbore reports t with an error of ~ulp(|o - v0|) /
+// cos(incidence), at grazing incidence up to ~1e-5 t BEFORE the ray enters the triangle's accurately tested box; with the old margin such a
+// triangle was tested or culled depending on the order the candidates came up in, and this tree, the product's tree and brute force could
+// each answer differently (found by the full-size C5 test).  Same constant as pt_bvh.h kCullSlack.
 inline bool slab(const BvhNode& n, const Ray& r, const float inv[3], float tbest) {
   const float* o = &r.origin.x;
-  float tn = r.min_distance, tf = tbest;
+  float tn = r.min_distance, tf = tbest * 1.0001f;
   for (int k = 0; k < 3; k++) {
     float t0 = (n.lo[k] - o[k]) * inv[k];
     float t1 = (n.hi[k] - o[k]) * inv[k];
@@ -1275,6 +1279,9 @@ float3 trace_path(const orc_scene& sc, uint32_t px, uint32_t py, uint32_t frameI
       break;
     }
     st.shaded++;
+    if (st.verbose)
+      fprintf(stderr, "  bounce %u hit inst %u prim %u t %.9g u %.9g v %.9g o (%.9g %.9g %.9g) d (%.9g %.9g %.9g)\n", bounce, isect.instance_id,
+              isect.primitive_id, isect.distance, isect.u, isect.v, ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x, ray.direction.y, ray.direction.z);
     const Hit hit = getIntersectionData(sc, ray, isect);
 
     float2 r01 = halton.sample2d();
@@ -1332,6 +1339,7 @@ float3 trace_path(const orc_scene& sc, uint32_t px, uint32_t py, uint32_t frameI
           float ir2 = halton.sample1d();
           st.shadow++;
           bool occluded = intersect_scene<true>(sc, shadow, ir2, tcs).hit;
+          if (st.verbose) fprintf(stderr, "  bounce %u shadow ray occluded %d tmax %.9g d (%.9g %.9g %.9g)\n", bounce, (int)occluded, shadow.max_distance, shadow.direction.x, shadow.direction.y, shadow.direction.z);
           if (!occluded) {
             float pdfLight = pLight * lightSample.pdf;
             float3 Ld = lightSample.Li * bsdfEval.f * fabsf(wi.z) / (pdfLight + bsdfEval.pdf);

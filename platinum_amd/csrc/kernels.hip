@@ -377,6 +377,10 @@ k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments se
   uint32_t ray = kInvalidRef;
   auto finish = [&]() {
     const RayHit& h = ts.best;
+#ifdef PT_DEBUG_PID
+    if (ts.dbg) printf("dbg finish: t %.9g u %.9g v %.9g tri %u gid %u\n", h.t, h.u, h.v, h.tri, h.gid >> 2);
+    ts.dbg = false;
+#endif
     hit[ray] = vec4{h.t, h.u, h.v, u2f(h.tri == kInvalidRef ? kInvalidRef : (h.tri | ((h.gid & 3u) << 28)))};
     if (hitlog) {
       // (the hit log is only kept for one-sample batches)
@@ -396,6 +400,10 @@ k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments se
       const vec4 d4 = st.rayD[ray];
       float ir = 0.0f;  // alpha-test payload: the sample drawn before `intersect` (kernel.metal:510), only needed with cut-outs
       if (S.has_alpha) ir = Halton{halton_table(S.halton), f2u(st.att[ray].w), f2u(d4.w) & kMetaDimMask}.sample1d();
+#ifdef PT_DEBUG_PID
+      ts.dbg = ctr->_pad[1] == bounce + 1u && segment_lbuf_base(seg, slot_segment(seg.nseg, ray)) + (f2u(d4.w) >> kMetaPidShift) == ctr->_pad[0];
+      if (ts.dbg) printf("dbg ray slot %u lane %u wave %u o %.9g %.9g %.9g d %.9g %.9g %.9g\n", ray, lane, wave_index(), o4.x, o4.y, o4.z, d4.x, d4.y, d4.z);
+#endif
       if (trav_init(S, ts, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 1e-3f, kInf, ir, stack, false, COUNT ? &tc : nullptr)) finish();
     }
     if (__ballot(ray != kInvalidRef) == 0) {

@@ -63,6 +63,17 @@ PT_HD void triangle_ids(const DeviceScene& S, uint32_t tri, int32_t* inst, int32
   *prim = (int32_t)((gid >> 2) - S.instances[in].tri_global_base);
 }
 
+// r5 — how far beyond the best hit so far a box is still visited.  fp32 Moeller-Trumbore's t carries an error of ~ulp(|o - v0|) / cos(incidence):
+// at grazing incidence it reports a hit up to ~1e-5 t BEFORE the ray enters that triangle's (accurately tested) box.  With the r1-r4 slack of
+// 5e-7 t such a triangle was culled or not depending on WHEN it came up — on the tree, and in the wave-cooperative kernels on which rays share
+// the wave: the full-size C5 parity test found 2 of 3.8e8 paths that differed between one 46-sample batch and the same samples in batches of
+// 16 (both camera rays at 78 degrees incidence on a column, hit within 1e-5 of a shared edge).  Boxes are now culled against best.t * (1 +
+// 1e-4): every candidate whose Moeller-Trumbore t is within 1e-4 t of the winner's is tested whatever the order.  That is 200x the old margin;
+// the rate of rays whose t error exceeds a margin falls with its square (it needs cos(incidence) < ~3 ulp / margin), i.e. from the observed
+// 5e-9 per ray to ~1e-13.  Not a proof: see DESIGN.md section 2 for what would be one (ranking hits by max(t, entry into the triangle's own
+// box): tools/experiments/r05_own_box_hit_rule.patch, correct and 12 % slower).
+constexpr float kCullSlack = 1.0001f;
+
 // Conservative slab test: entry distance or -1 if missed. fmin/fmax drop the NaN of 0 * inf.
 PT_HD float slab_entry(const float lo[3], const float hi[3], vec3 o, vec3 inv, float tmin, float tmax) {
   float t0 = (lo[0] - o.x) * inv.x, t1 = (hi[0] - o.x) * inv.x;
@@ -161,6 +172,9 @@ struct TravState {
   bool cnegx, cnegy, cnegz;
   float sx, sy, sz;       // slab slack in t per axis: (object-space position error bound of this ray in this instance) * |cinv|
   uint32_t tri_base;      // flattened index of the instance's first triangle: added to the BLAS leaf refs that are queued
+#ifdef PT_DEBUG_PID
+  bool dbg = false;       // debug build (tools/build_variant.sh dbg -DPT_DEBUG_PID): this lane's ray is the one $PTAMD_DEBUG_RAY names
+#endif
 };
 
 // intersections.metal:8-39 alphaTestIntersectionFunction: runs for every candidate hit on a non-opaque instance;
@@ -185,6 +199,13 @@ PT_HD bool alpha_test(const DeviceScene& S, uint32_t instanceIdx, uint32_t prim,
 // One candidate triangle against the ray's current best: the closest-hit rule (min t, ties to the lowest global id) or accept-any.
 PT_HD bool trav_test(const DeviceScene& S, TravState& ts, vec3 v0, vec3 v1, vec3 v2, uint32_t gid, uint32_t inst, bool cutouts, uint32_t tri, bool any) {
   float t, u, v;
+#if defined(PT_DEBUG_PID) && defined(__HIP_DEVICE_COMPILE__)
+  if (ts.dbg) {
+    float t2 = -1, u2 = -1, v2_ = -1;
+    const bool h2 = intersect_triangle(ts.o, ts.d, ts.tmin, kInf, v0, v1 - v0, v2 - v0, &t2, &u2, &v2_);
+    printf("dbg  test tri %u gid %u: hit(any t) %d t %.9g u %.9g v %.9g | best.t %.9g best.gid %u\n", tri, gid >> 2, (int)h2, t2, u2, v2_, ts.best.t, ts.best.gid >> 2);
+  }
+#endif
   if (!intersect_triangle(ts.o, ts.d, ts.tmin, ts.best.t, v0, v1 - v0, v2 - v0, &t, &u, &v)) return false;
   if (cutouts && !alpha_test(S, inst, (gid >> 2) - S.instances[inst].tri_global_base, u, v, ts.payload)) return false;
   if (any) { ts.best.tri = tri; return true; }
@@ -345,6 +366,7 @@ PT_HD void trav_node(const BvhNode* __restrict__ nodes, TravState& ts, Traversal
   const uint32_t nx = gx ? n.qhi[0] : n.qlo[0], fx = gx ? n.qlo[0] : n.qhi[0];
   const uint32_t ny = gy ? n.qhi[1] : n.qlo[1], fy = gy ? n.qlo[1] : n.qhi[1];
   const uint32_t nz = gz ? n.qhi[2] : n.qlo[2], fz = gz ? n.qlo[2] : n.qhi[2];
+  const float far_lim = ts.best.t * kCullSlack;
   float dist[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -354,7 +376,7 @@ PT_HD void trav_node(const BvhNode* __restrict__ nodes, TravState& ts, Traversal
     const float tny = __builtin_fmaf((float)((ny >> (8 * k)) & 0xffu), ay, bny), tfy = __builtin_fmaf((float)((fy >> (8 * k)) & 0xffu), ay, bfy);
     const float tnz = __builtin_fmaf((float)((nz >> (8 * k)) & 0xffu), az, bnz), tfz = __builtin_fmaf((float)((fz >> (8 * k)) & 0xffu), az, bfz);
     const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), ts.tmin);
-    const float tf = fminf(fminf(fminf(tfx, tfy), tfz), ts.best.t);
+    const float tf = fminf(fminf(fminf(tfx, tfy), tfz), far_lim);
     const bool hit = n.ref[k] != kInvalidRef && tn <= __builtin_fmaf(tf, 1.0000005f, 1e-30f);
     const bool leaf = hit && (n.ref[k] & kLeafBit);
     dist[k] = hit && !leaf ? tn : kInf;  // leaves never go on the node stack (TLAS leaves — kInstBit — do: they are entered like nodes)
@@ -444,6 +466,7 @@ PT_HD void trav_node6(const BvhNode* __restrict__ nodes, TravState& ts, Traversa
   const uint32_t ny2 = ts.negy ? n.q[1][2] >> 16 : n.q[1][2], fy2 = ts.negy ? n.q[1][2] : n.q[1][2] >> 16;
   const uint32_t nz2 = ts.negz ? n.q[2][2] >> 16 : n.q[2][2], fz2 = ts.negz ? n.q[2][2] : n.q[2][2] >> 16;
   const uint32_t n_int = n.counts & 7u, count = n_int + ((n.counts >> 3) & 7u);
+  const float far_lim = ts.best.t * kCullSlack;
   float best_d = kInf;
   uint32_t best_k = 0, hits = 0;  // hits: bit k = child k passed the slab test
 #pragma unroll
@@ -455,13 +478,16 @@ PT_HD void trav_node6(const BvhNode* __restrict__ nodes, TravState& ts, Traversa
     const float tny = __builtin_fmaf((float)qny, ay, by), tfy = __builtin_fmaf((float)qfy, ay, by);
     const float tnz = __builtin_fmaf((float)qnz, az, bz), tfz = __builtin_fmaf((float)qfz, az, bz);
     const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), ts.tmin);
-    const float tf = fminf(fminf(fminf(tfx, tfy), tfz), ts.best.t);
+    const float tf = fminf(fminf(fminf(tfx, tfy), tfz), far_lim);
     const bool hit = (uint32_t)k < count && tn <= __builtin_fmaf(tf, 1.0000005f, 1e-30f);
     hits |= hit ? 1u << k : 0u;
     const bool nearer = hit && (uint32_t)k < n_int && tn < best_d;
     best_d = nearer ? tn : best_d;
     best_k = nearer ? (uint32_t)k : best_k;
   }
+#if defined(PT_DEBUG_PID) && defined(__HIP_DEVICE_COMPILE__)
+  if (ts.dbg) printf("dbg node %u: n_int %u count %u hits %x base_node %u base_leaf %u best.t %.9g\n", ts.cur, n_int, count, hits, n.base_node, n.base_leaf, ts.best.t);
+#endif
   // leaf children that were hit: one queue entry (branch-free: no entry -> the scratch row)
   const uint32_t leaf_mask = hits >> n_int;
   ts.st.pend[(leaf_mask ? ts.st.npend : kPendLeaves6) * ts.st.lds_stride] = n.base_leaf << 6 | leaf_mask;

@@ -65,6 +65,16 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
   const bool count = mode == BATCH_MEASURE;
   Segments seg = r->segments();
   seg.nsamples = ns;
+#ifdef PT_DEBUG_PID
+  if (const char* e = getenv("PTAMD_DEBUG_RAY")) {  // debug build only: "x,y,sample,bounce" -> the closest-hit kernel prints that ray's traversal
+    uint32_t x = 0, y = 0, sm = 0, b = 0;
+    if (sscanf(e, "%u,%u,%u,%u", &x, &y, &sm, &b) == 4 && sm >= first && sm < first + ns) {
+      const uint32_t tilesX = (S.width + 7) / 8;
+      const uint32_t v[2] = {(((y >> 3) * tilesX + (x >> 3)) * 64u + (y & 7) * 8u + (x & 7)) * ns + (sm - first), b + 1u};
+      PT_HIP(hipMemcpyAsync(&ctr->_pad[0], v, 8, hipMemcpyHostToDevice, s));
+    }
+  }
+#endif
   {
     ScopedTimer t(r, K_RAYGEN);
     launch_raygen(s, r->grid, S, r->path_state(0), r->Lbuf.p, seg, ctr, first, ns);
@@ -108,6 +118,7 @@ int enqueue_batch(pt_renderer* r, uint32_t first, uint32_t ns, uint32_t n0, Batc
   // BATCH_DEBUG still folds (to clear the per-wave statistics) but into a scratch Totals slot
   launch_fold_counters(s, ctr, mode == BATCH_DEBUG ? r->totals.p + 1 : r->totals.p, seg, count);
   PT_HIP(hipGetLastError());
+  r->last_batch_ns = ns; r->last_batch_first = first;
   return PT_OK;
 }
 
@@ -566,6 +577,21 @@ int dev_wait(pt_renderer* r) {
       fprintf(stderr, "\nptamd chunks shadow:");
       for (uint32_t b = 0; b < r->S.max_bounces; b++) fprintf(stderr, " %u", h.chunks_shadow[b]);
       fprintf(stderr, "\n");
+    }
+  }
+  if (r->started && r->last_batch_ns) {
+    if (const char* e = getenv("PTAMD_DEBUG_PIXEL")) {  // analysis aid: "x,y" -> the per-sample radiance of that pixel in the LAST batch (Lbuf is [tile][pixel][sample])
+      uint32_t x = 0, y = 0;
+      if (sscanf(e, "%u,%u", &x, &y) == 2 && x < r->S.width && y < r->S.height) {
+        const uint32_t tilesX = (r->S.width + 7) / 8, ns = r->last_batch_ns;
+        std::vector<vec4> v(ns);
+        const size_t at = ((size_t)((y >> 3) * tilesX + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7)) * ns;
+        if (hipMemcpy(v.data(), r->Lbuf.p + at, sizeof(vec4) * ns, hipMemcpyDeviceToHost) == hipSuccess)
+          for (uint32_t k = 0; k < ns; k++) {
+            uint32_t b[3]; memcpy(b, &v[k], 12);
+            fprintf(stderr, "ptamd pixel %u,%u sample %u: %08x %08x %08x  %.9g %.9g %.9g\n", x, y, r->last_batch_first + k, b[0], b[1], b[2], v[k].x, v[k].y, v[k].z);
+          }
+      }
     }
   }
   if (r->started)

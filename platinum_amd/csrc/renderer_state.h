@@ -122,6 +122,7 @@ struct pt_renderer {
   pt_tonemap_options tonemap{};
   DevBuf<uint32_t> render_target;  // RGBA8 (renderer_pt.cpp:832-835)
   uint32_t closest_grid = 0, shadow_grid = 0, closest_blocks_per_cu = PT_CLOSEST_WAVES, shadow_blocks_per_cu = PT_SHADOW_WAVES;  // persistent trace grids, each sized for its kernel's occupancy
+  uint32_t last_batch_ns = 0, last_batch_first = 0;  // the batch Lbuf holds ($PTAMD_DEBUG_PIXEL)
   uint32_t nseg = 0, tiles_per_seg = 1, seg_bands = 4, tiles_per_seg_override = 0, nstats = 0, seg_cap = 0, blocks_per_cu = 6, shade_grid = 0, refill_threshold = 48;
   DevBuf<BatchCounters> ctr;
   DevBuf<Totals> totals;
