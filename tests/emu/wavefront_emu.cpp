@@ -821,6 +821,83 @@ void emu_packet_probe(void* h, uint32_t sample, double out[6]) {
     }
   out[0] = packets; out[1] = pn; out[2] = pt_; out[3] = rn; out[4] = rt; out[5] = mism;
 }
+// ---- experiment (emu_origin_sort_probe, r5): would sorting a segment's SECONDARY rays by the cell of their origin make its 64-ray chunks touch
+// fewer distinct lines?  The rays entering bounce `b` of ONE 8x8 tile under `ns` samples (a segment of the wavefront) are cut into 64-ray chunks
+// (a) in the order the stage leaves them (pixel-major, sample-minor, survivors compacted) and (b) sorted by the Morton code of their origin in a
+// 32^3 grid over the origins' bounds; per chunk: the number of DISTINCT 64-byte lines (6-wide nodes + leaf slots) its rays fetch, against the
+// sum over its rays.  out: {rays, chunks, lines summed over rays, distinct per chunk summed (arrival order), the same (sorted)}.  6-wide trees only.
+static void trace_lines(const DeviceScene& S, vec3 o, vec3 d, uint32_t* lds, uint32_t* spill, uint32_t* pend, std::vector<uint32_t>* lines) {
+  TraversalStack st; st.lds = lds; st.pend = pend; st.lds_stride = 1; st.spill = spill; st.spill_stride = 1;
+  TravState ts;
+  if (trav_init(S, ts, o, d, 1e-3f, kInf, 0.0f, st, false, nullptr)) return;
+  while (!(ts.cur == kInvalidRef && ts.st.npend == 0)) {
+    if (ts.cur != kInvalidRef && ts.st.npend <= kPendLeaves6 - 1) { lines->push_back(ts.cur); trav_node6<false>(S.nodes, ts, nullptr); }
+    while (ts.st.npend > 0) {
+      const uint32_t e = ts.st.pend[(ts.st.npend - 1) * ts.st.lds_stride];
+      lines->push_back(0x80000000u | ((e >> 6) + (uint32_t)__builtin_ctz(e & 63u)));
+      trav_pending_leaf6<false, false>(S, ts, nullptr);
+    }
+  }
+}
+void emu_origin_sort_probe(void* h, uint32_t tile_x, uint32_t tile_y, uint32_t ns, uint32_t bounce, double out[5]) {
+  Emu* e = (Emu*)h;
+  const DeviceScene& S = e->S;
+  for (int i = 0; i < 5; i++) out[i] = 0;
+  if (!S.wide6) return;
+  std::vector<uint32_t> lds(std::max(kLdsStack, kLdsStack6) + 1), spill(kSpillStack), pend(std::max(kPendLeaves, kPendLeaves6) + 1);
+  struct R { vec3 o, d; };
+  std::vector<R> rays;
+  for (uint32_t pl = 0; pl < 64; pl++)
+    for (uint32_t smp = 0; smp < ns; smp++) {
+      const uint32_t x = tile_x * 8 + (pl & 7), y = tile_y * 8 + (pl >> 3);
+      if (x >= S.width || y >= S.height) continue;
+      RayGenOut rg = stage_raygen(S, x, y, smp);
+      vec3 o = rg.o, d = rg.d, att = v3(1.0f);
+      float lastPdf = 0.0f; bool lastSpec = false; uint32_t dim = rg.dim;
+      bool alive = true;
+      for (uint32_t b = 0; b < bounce && alive; b++) {
+        TraversalStack st; st.lds = lds.data(); st.pend = pend.data(); st.lds_stride = 1; st.spill = spill.data(); st.spill_stride = 1;
+        const RayHit hit = traverse<false, false>(S, o, d, 1e-3f, kInf, 0.0f, st, nullptr);
+        if (hit.tri == kInvalidRef) { alive = false; break; }
+        const vec4 qO{o.x, o.y, o.z, lastPdf}, qD{d.x, d.y, d.z, 0.0f};
+        ShadeIn in; in.o = o; in.d = d; in.att = att; in.rayO = &qO; in.rayD = &qD; in.lastSpecular = lastSpec; in.offset = rg.offset;
+        in.dim = dim + 1; in.bounce = b; in.t = hit.t; in.u = hit.u; in.v = hit.v; in.tri = hit.tri;
+        const ShadeOut so = stage_shade(S, in);
+        if (!so.alive) { alive = false; break; }
+        o = so.next_o; d = so.next_d; att = so.next_att; lastPdf = so.next_pdf; lastSpec = so.next_specular; dim = so.dim & kMetaDimMask;
+      }
+      if (alive) rays.push_back({o, d});
+    }
+  if (rays.empty()) return;
+  std::vector<std::vector<uint32_t>> lines(rays.size());
+  double total = 0;
+  for (size_t i = 0; i < rays.size(); i++) { trace_lines(S, rays[i].o, rays[i].d, lds.data(), spill.data(), pend.data(), &lines[i]); total += (double)lines[i].size(); }
+  auto distinct = [&](const std::vector<uint32_t>& order) {
+    double sum = 0;
+    for (size_t c = 0; c < order.size(); c += 64) {
+      std::vector<uint32_t> u;
+      for (size_t k = c; k < std::min(order.size(), c + 64); k++) u.insert(u.end(), lines[order[k]].begin(), lines[order[k]].end());
+      std::sort(u.begin(), u.end());
+      sum += (double)(std::unique(u.begin(), u.end()) - u.begin());
+    }
+    return sum;
+  };
+  std::vector<uint32_t> order(rays.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+  const double arrival = distinct(order);
+  vec3 lo = rays[0].o, hi = rays[0].o;
+  for (auto& r : rays) { lo = v3(fminf(lo.x, r.o.x), fminf(lo.y, r.o.y), fminf(lo.z, r.o.z)); hi = v3(fmaxf(hi.x, r.o.x), fmaxf(hi.y, r.o.y), fmaxf(hi.z, r.o.z)); }
+  const float ext = fmaxf(fmaxf(hi.x - lo.x, hi.y - lo.y), fmaxf(hi.z - lo.z, 1e-20f));
+  std::vector<uint64_t> key(rays.size());
+  for (size_t i = 0; i < rays.size(); i++) {
+    const uint64_t cx = (uint64_t)fminf(31.0f, (rays[i].o.x - lo.x) / ext * 32.0f), cy = (uint64_t)fminf(31.0f, (rays[i].o.y - lo.y) / ext * 32.0f),
+                   cz = (uint64_t)fminf(31.0f, (rays[i].o.z - lo.z) / ext * 32.0f);
+    key[i] = expand21(cx) << 2 | expand21(cy) << 1 | expand21(cz);
+  }
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+  const double sorted = distinct(order);
+  out[0] = (double)rays.size(); out[1] = (double)((rays.size() + 63) / 64); out[2] = total; out[3] = arrival; out[4] = sorted;
+}
 void emu_get_wide(double out[26]) {
   int i = 0;
   const double r = g_wide.rays ? (double)g_wide.rays : 1.0;

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Host probe (tests/emu emu_origin_sort_probe): distinct 64-byte lines (6-wide nodes + leaf slots) the 64-ray chunks of a segment's SECONDARY rays
+fetch, in the order the shading stage leaves them against sorted by the cell of their origin.
+    python tools/origin_sort_probe.py c3 [samples=128]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.update(EMU_MORTON="1", EMU_PLOC="8", EMU_WIDE6="1", EMU_PAIRS="1")
+import emu_lib  # noqa: E402
+from platinum_amd import scenes  # noqa: E402
+from platinum_amd.renderer import make_params  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+ns = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+factory, W, H, spp, B = scenes.CONFIGS[wl]
+e = emu_lib.EmuScene(factory(), make_params(W, H, ns, B))
+e.L.emu_origin_sort_probe.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double * 5]
+tiles = [(tx, ty) for ty in range(8, H // 8, 25) for tx in range(10, W // 8, 45)]
+for b in (1, 2, 3, 5):
+    tot = [0.0] * 5
+    for tx, ty in tiles:
+        out = (C.c_double * 5)()
+        e.L.emu_origin_sort_probe(e.h, tx, ty, ns, b, out)
+        tot = [a + float(x) for a, x in zip(tot, out)]
+    rays, chunks, lines, arr, srt = tot
+    if rays:
+        print("%s bounce %d: %d tiles, %.0f rays per segment, lines per ray %.1f; distinct lines per 64-ray chunk: arrival %.1f (%.2f per ray), "
+              "origin-sorted %.1f (%.2f per ray): %+.1f %%" % (wl, b, len(tiles), rays / len(tiles), lines / rays, arr / chunks, arr / rays, srt / chunks, srt / rays, 100 * (srt / arr - 1)))
