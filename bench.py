@@ -509,6 +509,22 @@ def main():
         ks = r.stats()
         r.setProfiling(False)
 
+    # ---- counter calibration (--pmc-pass only): a streaming read of exactly known size through a kernel whose access pattern never changes -
+    # torch's vectorised copy of a 1 GiB tensor, 16 B per lane - so that tools/summarize_prof.py can check MI355X_MICROARCH.md's "FETCH_SIZE
+    # reports half of a wide coalesced streaming read" on THIS box in THIS pass (r4 derived it from k_accumulate, whose pattern r4 changed)
+    calib_copy = None
+    if args.pmc_pass and rank == 0:
+        nbytes, copies = 1 << 30, 3
+        src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        torch.cuda.synchronize(dev)
+        for _ in range(copies):
+            dst.copy_(src)
+        torch.cuda.synchronize(dev)
+        calib_copy = {"kernel_name_contains": "elementwise", "bytes_per_copy": nbytes, "copies": copies,
+                      "note": "dst.copy_(src) of 1 GiB float32: reads and writes exactly bytes_per_copy per dispatch (the normal_() fill writes only)"}
+        del src, dst
+
     lib_sha = library_sha16()
     pmc, pmc_src = load_pmc_profile(args.workload)
     if rank == 0 and pmc is not None:
@@ -580,6 +596,8 @@ def main():
             "library_sha16": lib_sha,
         },
     }
+    if calib_copy:
+        out["calibration_copy"] = calib_copy
 
     # ---- CPU baseline (rank 0, N = 1 only), bounded sample of the same workload ----
     # "the same __host__ __device__ kernels built for the host, all host cores" - tests/emu compiles the product's own

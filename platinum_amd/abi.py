@@ -273,11 +273,43 @@ def _torch_bundled_hip():
         return None
     if spec is None or not spec.submodule_search_locations:
         return None
+    import glob
     for d in spec.submodule_search_locations:
         p = os.path.join(d, "lib", "libamdhip64.so")
         if os.path.exists(p):
             return p
+        versioned = sorted(glob.glob(p + ".*"))   # a wheel that ships only the versioned file name
+        if versioned:
+            return versioned[0]
     return None
+
+
+def _elf_dynamic_strings(path, tag):
+    """DT_SONAME (tag 14) / DT_NEEDED (tag 1) strings of an ELF64 little-endian shared object, read without any tool; [] on any surprise."""
+    import struct
+    try:
+        with open(path, "rb") as f:
+            data = f.read()
+        if data[:4] != b"\x7fELF" or data[4] != 2 or data[5] != 1:
+            return []
+        shoff, = struct.unpack_from("<Q", data, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
+        secs = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+        out = []
+        for sec in secs:
+            if sec[1] != 6:      # SHT_DYNAMIC
+                continue
+            stroff = secs[sec[6]][4]   # sh_link -> .dynstr
+            for off in range(sec[4], sec[4] + sec[5], 16):
+                t, v = struct.unpack_from("<qQ", data, off)
+                if t == 0:
+                    break
+                if t == tag:
+                    end = data.index(b"\0", stroff + v)
+                    out.append(data[stroff + v:end].decode())
+        return out
+    except Exception:
+        return []
 
 
 def _settle_hip_runtime():
@@ -303,6 +335,14 @@ def _settle_hip_runtime():
     bundled = _torch_bundled_hip()
     if bundled is None:
         return "system (no torch with a bundled runtime in this interpreter)"
+    # The preload only helps if libptamd.so's DT_NEEDED names the SONAME of torch's copy (libamdhip64.so.7 on both sides in this image).  A
+    # torch wheel built for another ROCm major carries another soname: preloading it would put a runtime into the process that libptamd.so
+    # does not bind to, /opt/rocm's would be mapped beside it, and every pt_create would fail with "two GPU runtimes" (ADVICE r4).
+    soname = _elf_dynamic_strings(bundled, 14)
+    needed = [n for n in _elf_dynamic_strings(library_path(), 1) if n.startswith("libamdhip64.so")]
+    if soname and needed and soname[0] not in needed:
+        return ("system (torch bundles %s, libptamd.so needs %s: a different ROCm major - not preloaded; do not import torch in this process, "
+                "or build libptamd.so against torch's ROCm)" % (soname[0], needed[0]))
     C.CDLL(bundled, mode=C.RTLD_GLOBAL)
     return "preloaded torch's bundled runtime: " + bundled
 
@@ -342,7 +382,9 @@ def load_library(path=None):
     lib.pt_get_runtime_info(C.byref(ri))
     if ri.hip_runtimes_mapped > 1:   # (two libhsa-runtime64 under ONE HIP runtime is what rocprofv3's tool library gives: legitimate)
         raise PtamdError("two GPU runtimes are mapped into this process (" + ri.all_mapped.decode() + "): only the one that initialises "
-                         "first would see the GPU.  Import torch, or platinum_amd, before anything else that links /opt/rocm's libamdhip64")
+                         "first would see the GPU.  Import torch, or platinum_amd, before anything else that links /opt/rocm's libamdhip64; "
+                         "in a process that never uses torch, $PTAMD_HIP_RUNTIME=system keeps /opt/rocm's runtime alone (how the HIP runtime was settled: "
+                         + str(_runtime_note) + ")")
     if path is None:
         _lib = lib
         _runtime_note = note

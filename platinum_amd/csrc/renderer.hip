@@ -397,7 +397,9 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
     {
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-      const uint64_t flat_bytes = (uint64_t)r->tri_count * 260ull;  // TriRec + nodes + ShadeRec + the builder's scratch at its peak
+      // TriRec + nodes + ShadeRec + the builder's scratch at its peak.  Worst case: no triangle finds a partner (a soup, $PTAMD_NO_PAIRS) — one 64-byte
+      // slot and TWO 32-byte shade records (entry 2 * slot + half; the B entries unused) per triangle, 32 B more than a paired mesh
+      const uint64_t flat_bytes = (uint64_t)r->tri_count * 292ull;
       r->two_level = invertible && (uint64_t)r->tri_count >= 8 * unique_tris && free_b != 0 && flat_bytes > free_b / 2;
     }
     if (p->accel_structure == PT_ACCEL_ONE_BVH) r->two_level = false;

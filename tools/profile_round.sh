@@ -6,7 +6,7 @@
 # then tools/summarize_prof.py (newest output of each pass) writes profiles/<tag>_<wl>_{summary.md,kernel_stats.csv} and
 # profiles/<round>_pmc_<wl>.json.
 set -u
-WL=$1; TAG=${2:-r04}; OUT=gpurun_out/prof; mkdir -p $OUT
+WL=$1; TAG=${2:-r05}; OUT=gpurun_out/prof; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${WL}_trace -- python3 bench.py --workload $WL --no-cpu-baseline > $OUT/${WL}_bench_under_rocprof.json 2> $OUT/${WL}_trace.err || echo "trace pass failed"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${WL}_fetch -- python3 bench.py --workload $WL --pmc-pass --steps 2 > $OUT/${WL}_fetch.json 2> $OUT/${WL}_fetch.err || echo "fetch pass failed"

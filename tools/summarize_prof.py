@@ -54,14 +54,19 @@ if stats:
         d["calls"] += int(r["Calls"]); d["total_ms"] += float(r["TotalDurationNs"]) / 1e6
 
 
+RAW_ROWS = {}   # kind -> [(full kernel name, counter, value)] of that pass (the calibration copy is found by its full name)
+
+
 def counters(kind):
     """{kernel: {counter: [dispatches, sum]}} of one --pmc pass, and that pass's bench JSON (item counts)."""
     f = newest(os.path.join(prof_dir, f"{wl}_{kind}", "**", "*_counter_collection.csv"))
     acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    RAW_ROWS[kind] = []
     if f:
         for r in csv.DictReader(open(f)):
             a = acc[short(r["Kernel_Name"])][r["Counter_Name"]]
             a[0] += 1; a[1] += float(r["Counter_Value"])
+            RAW_ROWS[kind].append((r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])))
     try:
         j = json.loads([l for l in open(os.path.join(prof_dir, f"{wl}_{kind}.json")) if l.startswith("{")][-1])
     except Exception:
@@ -89,14 +94,45 @@ def items(j):
 itf, itw, its, itt = items(jf), items(jw), items(js), items(jt)
 
 # ---- calibration on known byte counts ----
+# (r5) The streaming factor comes from a kernel whose access pattern does not change between rounds: the 1 GiB `dst.copy_(src)` bench.py runs at
+# the end of every --pmc pass (torch's vectorised copy, 16 B per lane).  r2-r4 derived it from k_accumulate, whose reads r4 rewrote: with 46
+# samples per pixel (C5) a pixel's samples are not whole 128-byte lines and the "factor" came out as 1.15.  k_accumulate is still reported, as
+# a second opinion where its reads ARE whole lines (samples per step a multiple of 8).  MI355X_MICROARCH.md section HBM prescribes exactly 2 for
+# wide coalesced streaming reads: a measured factor outside [1.9, 2.1] is an error, not a number to use.
 calib = {}
+
+
+def copy_factor(kind, counter, j):
+    c = (j or {}).get("calibration_copy")
+    if not c:
+        return None, None
+    vals = [v for (name, cn, v) in RAW_ROWS.get(kind, []) if cn == counter and c["kernel_name_contains"] in name]
+    # the copies are the dispatches of that name that moved the most bytes (the fill kernels of the same family read nothing)
+    vals = sorted(vals, reverse=True)[: c["copies"]]
+    if len(vals) < c["copies"] or min(vals) <= 0:
+        return None, None
+    raw = sum(vals) * 1024.0
+    return c["bytes_per_copy"] * c["copies"] / raw, raw
+
+
+ff_copy, raw_copy = copy_factor("fetch", "FETCH_SIZE", jf)
+wf_copy, _ = copy_factor("write", "WRITE_SIZE", jw)
+if ff_copy is not None:
+    calib["fetch_streaming_factor"] = ff_copy
+    calib["fetch_streaming_factor_source"] = "1 GiB torch copy x %d (bench.py --pmc-pass), FETCH_SIZE raw %.0f bytes" % (jf["calibration_copy"]["copies"], raw_copy)
+if wf_copy is not None:
+    calib["write_factor_copy"] = wf_copy
 if "k_accumulate" in fetch and itf:
     S = itf["_spp_per_step"]
     expect = itf["_npix"] * (S + 1) * 16.0 * itf["_steps"]
     raw = fetch["k_accumulate"]["FETCH_SIZE"][1] * 1024.0
-    calib["fetch_streaming_factor"] = expect / raw if raw else None
+    calib["k_accumulate_fetch_factor"] = expect / raw if raw else None
+    calib["k_accumulate_whole_lines"] = bool(S % 8 == 0)
     calib["k_accumulate_read_bytes_expected"] = expect
     calib["k_accumulate_FETCH_SIZE_bytes_raw"] = raw
+    if "fetch_streaming_factor" not in calib and S % 8 == 0:
+        calib["fetch_streaming_factor"] = calib["k_accumulate_fetch_factor"]
+        calib["fetch_streaming_factor_source"] = "k_accumulate (no calibration copy in this pass)"
 if "k_accumulate" in write and itw:
     expect = itw["_npix"] * 16.0 * itw["_steps"]
     raw = write["k_accumulate"]["WRITE_SIZE"][1] * 1024.0
@@ -107,7 +143,13 @@ if "k_raygen" in write and itw:
     calib["write_factor_k_raygen"] = expect / raw if raw else None
     calib["k_raygen_write_bytes_expected"] = expect
     calib["k_raygen_WRITE_SIZE_bytes_raw"] = raw
-ff = calib.get("fetch_streaming_factor") or 2.0
+ff = calib.get("fetch_streaming_factor")
+if fetch and ff is None:
+    sys.exit("summarize_prof.py: no streaming calibration in the fetch pass (no calibration copy, and k_accumulate's reads are not whole lines at %s samples per step): re-run tools/profile_round.sh" % (itf.get("_spp_per_step") if itf else "?"))
+if ff is not None and not (1.9 <= ff <= 2.1):
+    sys.exit("summarize_prof.py: streaming-read calibration %.3f is outside [1.9, 2.1] (MI355X_MICROARCH.md section HBM: exactly 2 for wide coalesced reads) - "
+             "the counter pass is not usable as it stands (%s)" % (ff, calib.get("fetch_streaming_factor_source")))
+ff = ff or 2.0
 # Random 64-byte gathers (what the traversal kernels fetch) are reported exactly: profiles/r02_calib_gather.md
 GATHER_FACTOR = {"k_trace_closest": 1.0, "k_trace_shadow": 1.0, "k_trace_closest[two-level]": 1.0, "k_trace_shadow[two-level]": 1.0}
 # k_shade reads BOTH kinds: per hit it streams its queue entry (hit 16 B + rayO 16 + rayD 16 + att 16 + the 4-byte
