@@ -510,7 +510,7 @@ def main():
         r.setProfiling(False)
 
     # ---- counter calibration (--pmc-pass only): a streaming read of exactly known size through a kernel whose access pattern never changes -
-    # torch's vectorised copy of a 1 GiB tensor, 16 B per lane - so that tools/summarize_prof.py can check MI355X_MICROARCH.md's "FETCH_SIZE
+    # torch's vectorised elementwise kernel over a 1 GiB tensor, 16 B per lane - so that tools/summarize_prof.py can check MI355X_MICROARCH.md's "FETCH_SIZE
     # reports half of a wide coalesced streaming read" on THIS box in THIS pass (r4 derived it from k_accumulate, whose pattern r4 changed)
     calib_copy = None
     if args.pmc_pass and rank == 0:
@@ -519,10 +519,10 @@ def main():
         dst = torch.empty_like(src)
         torch.cuda.synchronize(dev)
         for _ in range(copies):
-            dst.copy_(src)
+            torch.add(src, 1.0, out=dst)   # (dst.copy_(src) would go through hipMemcpyDtoD's blit kernel)
         torch.cuda.synchronize(dev)
-        calib_copy = {"kernel_name_contains": "elementwise", "bytes_per_copy": nbytes, "copies": copies,
-                      "note": "dst.copy_(src) of 1 GiB float32: reads and writes exactly bytes_per_copy per dispatch (the normal_() fill writes only)"}
+        calib_copy = {"kernel_name_contains": "vectorized_elementwise_kernel", "bytes_per_copy": nbytes, "copies": copies,
+                      "note": "torch.add(src, 1.0, out=dst) on 1 GiB float32: reads and writes exactly bytes_per_copy per dispatch (the normal_() fill writes only)"}
         del src, dst
 
     lib_sha = library_sha16()

@@ -1,13 +1,19 @@
 # usage (GPU box): bash tools/r05_final.sh <tag> — GPU suite, the rocprofv3 passes for C3 / C2 / C5 (tools/profile_round.sh; their logs are KEPT and a failed
 # pass or a stale counter file stops the script: ADVICE r4), then the bench lines: default (C3), C2, C5, the drop-in render(1) loop, logical-shard
 # rehearsals on one GPU (labelled REHEARSAL, no RCCL), two-level
-tag=${1:-r05a}
+# stage (2nd argument): "profiles" = suite + rocprofv3 passes only (copy gpurun_out/profiles_out/* into profiles/ afterwards: only gpurun_out/ comes
+# back from the box), "bench" = the bench lines only (reads the committed profiles/r05_pmc_*.json), default = both in one call
+tag=${1:-r05a}; stage=${2:-all}
 fail() { echo "r05_final: $*"; exit 1; }
+if [ "$stage" != bench ]; then
 timeout -k 10 900 python -m pytest tests -m gpu -x -q -s > gpurun_out/${tag}_tests.log 2>&1; tail -3 gpurun_out/${tag}_tests.log; grep "full size" gpurun_out/${tag}_tests.log
 for w in c3 c2 c5; do
   bash tools/profile_round.sh $w ${tag} > gpurun_out/${tag}_profile_$w.log 2>&1
   grep -n "pass failed\|summary failed\|summarize_prof.py:" gpurun_out/${tag}_profile_$w.log && fail "profile pass of $w failed (gpurun_out/${tag}_profile_$w.log)"
 done
+mkdir -p gpurun_out/profiles_out; cp profiles/${tag}_* profiles/r05_pmc_* gpurun_out/profiles_out/ 2>/dev/null; cp gpurun_out/prof/*_bench_under_rocprof.json gpurun_out/profiles_out/ 2>/dev/null; ls gpurun_out/profiles_out | head -30
+fi
+[ "$stage" = profiles ] && exit 0
 bench() { # name timeout args...
   n=$1; t=$2; shift 2
   timeout -k 10 $t python bench.py "$@" > gpurun_out/${tag}_$n.json 2> gpurun_out/${tag}_$n.err || { tail -8 gpurun_out/${tag}_$n.err; fail "bench $n failed"; }

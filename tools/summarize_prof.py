@@ -94,7 +94,7 @@ def items(j):
 itf, itw, its, itt = items(jf), items(jw), items(js), items(jt)
 
 # ---- calibration on known byte counts ----
-# (r5) The streaming factor comes from a kernel whose access pattern does not change between rounds: the 1 GiB `dst.copy_(src)` bench.py runs at
+# (r5) The streaming factor comes from a kernel whose access pattern does not change between rounds: the 1 GiB `torch.add(src, 1, out=dst)` bench.py runs at
 # the end of every --pmc pass (torch's vectorised copy, 16 B per lane).  r2-r4 derived it from k_accumulate, whose reads r4 rewrote: with 46
 # samples per pixel (C5) a pixel's samples are not whole 128-byte lines and the "factor" came out as 1.15.  k_accumulate is still reported, as
 # a second opinion where its reads ARE whole lines (samples per step a multiple of 8).  MI355X_MICROARCH.md section HBM prescribes exactly 2 for
@@ -119,7 +119,7 @@ ff_copy, raw_copy = copy_factor("fetch", "FETCH_SIZE", jf)
 wf_copy, _ = copy_factor("write", "WRITE_SIZE", jw)
 if ff_copy is not None:
     calib["fetch_streaming_factor"] = ff_copy
-    calib["fetch_streaming_factor_source"] = "1 GiB torch copy x %d (bench.py --pmc-pass), FETCH_SIZE raw %.0f bytes" % (jf["calibration_copy"]["copies"], raw_copy)
+    calib["fetch_streaming_factor_source"] = "1 GiB torch elementwise pass x %d (bench.py --pmc-pass), FETCH_SIZE raw %.0f bytes" % (jf["calibration_copy"]["copies"], raw_copy)
 if wf_copy is not None:
     calib["write_factor_copy"] = wf_copy
 if "k_accumulate" in fetch and itf:
