@@ -861,7 +861,7 @@ def test_rays_in_a_triangles_plane_miss_it_whatever_structure_is_walked(gpu_rend
     tree = oracle_lib.OracleScene(sc, p, use_bvh=True).render(first, spp)
     brute = oracle_lib.OracleScene(sc, p, use_bvh=False).render(first, spp)
     assert _same_bits_or_both_nan(tree, brute)
-    if two_level:
+    if two_level and seed == 310601:   # THE named case, not a tolerance of the two-level path: every other two-level test demands the same bits
         differing = np.argwhere((acc.view(np.uint32) != tree.view(np.uint32)).any(-1))
         assert len(differing) <= 1 and np.nanmax(np.abs(acc - tree)) < 1e-5 and np.array_equal(np.isnan(acc), np.isnan(tree))
     else:
