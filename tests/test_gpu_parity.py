@@ -868,6 +868,33 @@ def test_rays_in_a_triangles_plane_miss_it_whatever_structure_is_walked(gpu_rend
         assert _same_bits_or_both_nan(acc, tree)
 
 
+def test_where_the_oracles_tree_and_brute_force_part_the_product_follows_brute_force(gpu_renderer):
+    """r5, found by 60 000 new fuzz seeds after the cull margin was widened (seed 800642, extras): ONE shadow ray whose any-hit answer differs between
+    the oracle's own BVH and the oracle's brute-force loop — the contract's definition — because fp32 Moeller-Trumbore accepts a triangle the ray
+    passes outside of (a false hit, DESIGN.md section 2 case 2): brute force tests every triangle, the oracle's tight per-triangle boxes never reach
+    that one, the product's pair-slot boxes do.  The product equals BRUTE FORCE bit for bit; the oracle's tree differs from both in one pixel-sample
+    by 3e-7.  Kept as what it is: evidence that "equal to the oracle" means "equal to the contract", and that the oracle's tree is only a fast way
+    to evaluate it that is right all but once in ~1e9 rays."""
+    seed = 800642
+    sc = scenes.random_scene(seed, extras=True)
+    w, h, B = 96, 54, 3 + seed % 7
+    flags = abi.FLAG_MULTISCATTER_GGX if seed % 5 else 0
+    space = scenes.BT2020 if seed % 7 else scenes.BT709
+    first, spp, sif = (seed % 13) * 3, 2 + seed % 4, 1 + seed % 5
+    integ = abi.INTEGRATOR_MIS if seed % 4 else abi.INTEGRATOR_SIMPLE
+    gpu_renderer.selectKernel(integ)
+    gpu_renderer.startRender(sc, (w, h), spp, workingSpace=space, flags=flags, max_bounces=B, first_sample=first, samples_in_flight=sif)
+    gpu_renderer.render(0)
+    acc = gpu_renderer.readbackAccumulator()
+    gpu_renderer.selectKernel(abi.INTEGRATOR_MIS)
+    p = make_params(w, h, spp, B, flags=flags, integrator=integ, working_space=space, first_sample=first)
+    brute = oracle_lib.OracleScene(sc, p, use_bvh=False).render(first, spp)
+    tree = oracle_lib.OracleScene(sc, p, use_bvh=True).render(first, spp)
+    assert _same_bits_or_both_nan(acc, brute)
+    differing = np.argwhere((tree.view(np.uint32) != brute.view(np.uint32)).any(-1))
+    assert len(differing) <= 1 and np.nanmax(np.abs(tree - brute)) < 1e-5
+
+
 @pytest.mark.parametrize("seed", list(range(24)) + [1000 + i for i in range(12)])
 def test_random_scene_fuzz_parity(gpu_renderer, seed):
     """36 seeded random scenes (scenes.random_scene) through the HIP path against the oracle: hit ids, per-sample radiance and
