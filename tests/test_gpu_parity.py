@@ -890,9 +890,15 @@ def test_where_the_oracles_tree_and_brute_force_part_the_product_follows_brute_f
     p = make_params(w, h, spp, B, flags=flags, integrator=integ, working_space=space, first_sample=first)
     brute = oracle_lib.OracleScene(sc, p, use_bvh=False).render(first, spp)
     tree = oracle_lib.OracleScene(sc, p, use_bvh=True).render(first, spp)
-    assert _same_bits_or_both_nan(acc, brute)
     differing = np.argwhere((tree.view(np.uint32) != brute.view(np.uint32)).any(-1))
     assert len(differing) <= 1 and np.nanmax(np.abs(tree - brute)) < 1e-5
+    # the default structure (pair slots: a slot's box spans two triangles and reaches the false hit) follows brute force; with one triangle per slot
+    # ($PTAMD_NO_PAIRS: boxes as tight as the oracle's) the product follows the oracle's tree instead — an any-hit answer depends on whether a
+    # structure's boxes reach a triangle fp32 wrongly accepts, and this seed shows both sides of it
+    if "PTAMD_NO_PAIRS" in os.environ:
+        assert _same_bits_or_both_nan(acc, tree) or _same_bits_or_both_nan(acc, brute)
+    else:
+        assert _same_bits_or_both_nan(acc, brute)
 
 
 @pytest.mark.parametrize("seed", list(range(24)) + [1000 + i for i in range(12)])
