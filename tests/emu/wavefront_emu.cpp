@@ -19,6 +19,7 @@ using namespace pt;
 namespace {
 
 static unsigned long long g_nodes = 0, g_tris = 0, g_rays = 0, g_leaves = 0;  // traversal statistics of emu_debug_sample (experiments)
+static unsigned long long g_pb_nodes[16] = {0}, g_pb_tris[16] = {0}, g_pb_leaves[16] = {0}, g_pb_rays[16] = {0};  // ... per bounce
 
 struct Emu {
   HostScene hs;
@@ -612,6 +613,7 @@ void emu_debug_sample(void* h, uint32_t sample, float* radiance /*W*H*4*/, int32
         const float ir = S.has_alpha ? Halton{halton_table(S.halton), rg.offset, dim}.sample1d() : 0.0f;
         RayHit hit = traverse<false, true>(S, o, d, 1e-3f, kInf, ir, st, &tc);
         g_nodes += tc.nodes; g_tris += tc.tris; g_leaves += tc.leaves; g_rays++;
+        if (b < 16) { g_pb_nodes[b] += tc.nodes; g_pb_tris[b] += tc.tris; g_pb_leaves[b] += tc.leaves; g_pb_rays[b]++; }
         if (!e->wide[8].empty() && !S.has_alpha) {
           for (int N : {4, 6, 8})
             for (int rule = 0; rule < 3; rule++) {
@@ -912,6 +914,10 @@ void emu_get_probe(unsigned long long out[6]) {
   g_probe = ProbeCounts{};
 }
 uint32_t emu_slot_count(void* h) { return ((Emu*)h)->S.slot_count; }
+// per-bounce counts of the closest-hit rays of emu_debug_sample (r5 probe): out[16][4] = {nodes, triangle tests, leaf fetches, rays}
+void emu_get_counts_per_bounce(unsigned long long out[64]) {
+  for (int b = 0; b < 16; b++) { out[4 * b] = g_pb_nodes[b]; out[4 * b + 1] = g_pb_tris[b]; out[4 * b + 2] = g_pb_leaves[b]; out[4 * b + 3] = g_pb_rays[b]; g_pb_nodes[b] = g_pb_tris[b] = g_pb_leaves[b] = g_pb_rays[b] = 0; }
+}
 void emu_get_counts(unsigned long long out[4]) { out[0] = g_nodes; out[1] = g_tris; out[2] = g_rays; out[3] = g_leaves; g_nodes = g_tris = g_rays = g_leaves = 0; }
 float emu_halton(void* h, uint32_t i, uint32_t d) { return halton(halton_table(((Emu*)h)->halton.data()), i, d); }
 
