@@ -6,6 +6,7 @@ CPU: the partition arithmetic (pt_group_partition).  GPU (one device is enough: 
 with their own host threads, streams, scene copies and accumulators, merged by the same code path minus RCCL; with two
 or more devices present the RCCL all-reduce itself is exercised)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -274,3 +275,26 @@ def test_two_physical_devices_rccl_all_reduce():
     got, _, rn = _render([0, 1], sc, 8)
     rn.close()
     np.testing.assert_allclose(got[..., :3], ref[..., :3], rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_runs_two_ranks_on_this_gpu_and_relays_one_json_line():
+    """`python bench.py --gpus 2` as the driver may start it WITHOUT a launcher, rehearsed on the one GPU of this box (every rank on device 0, gloo
+    for the reduce since RCCL refuses two ranks on one device): the parent starts torch.distributed.run as a child before touching the GPU, the two
+    ranks shard the samples, reduce the accumulator and take the max-over-ranks time, rank 0's line comes back through the parent, and every rank's
+    start-up lines (rank, device, process group, runtime) are on stderr.  What differs on an 8-GPU node is the backend name and the device ordinal."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-device0", "--workload", "c1", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-kernel-pass", "--launch-timeout", "300"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
+    assert p.returncode == 0, (p.returncode, p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["config"]["logical_shards"] == 2 and d["n_gpus"] == 1 and "REHEARSAL" in d["config"]["parallelism"] and d["value"] > 0
+    assert d["config"]["spp_total"] == 2 * d["config"]["spp_per_gpu"] and d["extra"]["paths"] > 0
+    for r in (0, 1):
+        assert "[rank %d] bench.py[rank %d/2" % (r, r) in p.stderr and "process group up: backend gloo" in p.stderr and "renderer on device 0" in p.stderr
