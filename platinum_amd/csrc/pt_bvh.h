@@ -253,7 +253,13 @@ PT_HD bool trav_init(const DeviceScene& S, TravState& ts, vec3 o, vec3 d, float 
   // dropped by fmin/fmax, i.e. the axis stops constraining anything and an axis-parallel ray walks a large part of the
   // tree (measured: environment-light shadow rays towards the top row of a lat-long map, direction exactly (0,1,0),
   // made k_trace_shadow 250x slower).  A huge finite reciprocal keeps the slab test exact in the limit.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PT_EXACT_RAY_RCP)
+  // the reciprocal direction only feeds the slab tests, whose arithmetic has to be conservative, not reproducible (trav_node): v_rcp_f32
+  // (1 ulp) instead of three IEEE divisions (~8 instructions each, run for the few lanes of a refill)
+  ts.inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+#else
   ts.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+#endif
   if (!(fabsf(ts.inv.x) <= 1e30f)) ts.inv.x = copysignf(1e30f, d.x);
   if (!(fabsf(ts.inv.y) <= 1e30f)) ts.inv.y = copysignf(1e30f, d.y);
   if (!(fabsf(ts.inv.z) <= 1e30f)) ts.inv.z = copysignf(1e30f, d.z);
