@@ -3,7 +3,7 @@
 # rehearsals on one GPU (labelled REHEARSAL, no RCCL), two-level
 # stage (2nd argument): "profiles" = suite + rocprofv3 passes only (copy gpurun_out/profiles_out/* into profiles/ afterwards: only gpurun_out/ comes
 # back from the box), "bench" = the bench lines only (reads the committed profiles/r05_pmc_*.json), default = both in one call
-tag=${1:-r05a}; stage=${2:-all}
+tag=${1:-r05b}; stage=${2:-all}
 fail() { echo "r05_final: $*"; exit 1; }
 if [ "$stage" != bench ]; then
 timeout -k 10 900 python -m pytest tests -m gpu -x -q -s > gpurun_out/${tag}_tests.log 2>&1; tail -3 gpurun_out/${tag}_tests.log; grep "full size" gpurun_out/${tag}_tests.log
