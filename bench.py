@@ -128,7 +128,7 @@ def parse_args(argv=None):
     ap.add_argument("--launch-timeout", type=float, default=0.0,
                     help="N > 1 started without a launcher: seconds after which the parent ends the rank processes and reports their last lines "
                          "(default %.0f)" % LAUNCH_TIMEOUT_S)
-    ap.add_argument("--rank-timeout", type=float, default=480.0,
+    ap.add_argument("--rank-timeout", type=float, default=540.0,
                     help="N > 1: seconds after which a rank that has not finished dumps its Python stacks to stderr and exits (no GPU call is made "
                          "by the watchdog); 0 = off")
     ap.add_argument("--spp", type=int, default=0, help="--strong: total samples per pixel of the render (default: the workload's full spp, 1024 for c3 = C4)")
