@@ -135,7 +135,7 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-LAUNCH_TIMEOUT_S = 420.0   # wall limit of a self-launched N-rank run: below the driver's 600 s, so that a stalled rendezvous is reported by
+LAUNCH_TIMEOUT_S = 540.0   # wall limit of a self-launched N-rank run: below the driver's 600 s, so that a stalled rendezvous is reported by
                            # THIS process (each rank's last lines) instead of the whole job being killed "for writing nothing"
 
 
