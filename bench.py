@@ -398,6 +398,14 @@ def main():
             free_b //= max(_d.count(x) for x in set(_d))
         abi.check(abi.load_library(), abi.load_library().pt_plan_queues(W, H, 1 << 20, 0, int(free_b), 0, 4, _C.byref(plan)))
         S = int(plan.samples_in_flight)
+        if dist is not None:
+            # every rank must trace the SAME batch size: the sample ranges [g * K * S, (g + 1) * K * S) tile the render only then (a GPU with
+            # less free memory would plan a smaller batch on its own)
+            t = torch.tensor([S], dtype=torch.int64, device="cpu" if args.rehearse_on_device0 else torch.device("cuda", local_rank))
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) != S:
+                say("planned %d samples in flight, the job runs %d (the smallest plan of all ranks)" % (S, int(t.item())))
+            S = int(t.item())
     ndev_all = args.gpus if (args.inproc and args.gpus > 1) else world
     strong_spp = 0
     if args.strong:
