@@ -9,6 +9,7 @@
     set — with the oracle's running mean over the same samples (`orc_render_pixels`: the loop of `orc_render` for a list of pixels),
     BIT FOR BIT (kernel.metal:672-684);
   * compares the ray / shadow-ray / shaded-hit counters of a full-size two-sample render with the oracle's whole-frame counters;
+  * renders a second planned batch on top and compares the probe pixels again (the running mean's weights with samples already in it);
   * requires the whole 128-in-flight image to equal, bit for bit, the image the same library produces in batches of 16 (different segment
     fill, different chunk tables, different accumulate folds — the same samples in the same order).
 """
@@ -99,17 +100,27 @@ def _full_size_case(r, scene, W, H, B, spp_expected=None, counters_spp=2):
     acc = r.readbackAccumulator()
     xy = _probe_pixels(W, H, ids)
     ref = o.render_pixels(xy, 0, S)
-    o.close()
     got = acc[xy[:, 1], xy[:, 0]]
     bad = ~((got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))).all(axis=1)
     assert not bad.any(), "pixels %s: HIP %s oracle %s" % (xy[bad][:4].tolist(), got[bad][:4].tolist(), ref[bad][:4].tolist())
     assert (acc[..., 3] == 1).all() and np.nanmean(acc[..., :3]) > 1e-3
+    # ---- a SECOND planned batch on top (samples S .. 2S-1 folded into a mean that already holds S): the running-mean weights at full size --
+    r.startRender(scene, (W, H), 2 * S, max_bounces=B, samples_in_flight=S)
+    r.render(0)
+    r.wait()
+    assert r.stats().batches == 2
+    acc2 = r.readbackAccumulator()
+    xy2 = xy[::4]   # (a quarter of the probe pixels: the oracle walks 2 S samples for each)
+    ref2 = o.render_pixels(xy2, 0, 2 * S)
+    got2 = acc2[xy2[:, 1], xy2[:, 0]]
+    assert (((got2.view(np.uint32) == ref2.view(np.uint32)) | (np.isnan(got2) & np.isnan(ref2))).all(axis=1)).all()
     # ---- the same samples in batches of 16: the whole image, bit for bit --------------------------------------------------------------
     r.startRender(scene, (W, H), S, max_bounces=B, samples_in_flight=16)
     r.render(0)
     r.wait()
     assert r.stats().batches == -(-S // 16)
     assert _same_bits_or_both_nan(r.readbackAccumulator(), acc)
+    o.close()
     return S, len(xy), time.perf_counter() - t_start
 
 
