@@ -131,6 +131,7 @@ def parse_args(argv=None):
     ap.add_argument("--rank-timeout", type=float, default=540.0,
                     help="N > 1: seconds after which a rank that has not finished dumps its Python stacks to stderr and exits (no GPU call is made "
                          "by the watchdog); 0 = off")
+    ap.add_argument("--test-stall-after-start", action="store_true", help=argparse.SUPPRESS)   # tests/test_multi_gpu_gloo.py only: a rank that never comes back
     ap.add_argument("--spp", type=int, default=0, help="--strong: total samples per pixel of the render (default: the workload's full spp, 1024 for c3 = C4)")
     return ap.parse_args(argv)
 
@@ -183,7 +184,10 @@ def self_launch(args):
     t0 = time.monotonic()
     print("bench.py[launcher pid %d]: starting %d ranks (limit %.0f s, per-rank logs under %s)" % (os.getpid(), args.gpus, limit, log_dir),
           file=sys.stderr, flush=True)
-    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    # the launcher's own stdout / stderr go to FILES (an undrained PIPE blocks torchrun as soon as it has written ~64 KiB while its ranks fail)
+    l_out_path, l_err_path = os.path.join(log_dir, "launcher_stdout.log"), os.path.join(log_dir, "launcher_stderr.log")
+    with open(l_out_path, "w") as fo, open(l_err_path, "w") as fe:
+        child = subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL, start_new_session=True)
     print("bench.py[launcher]: ranks run in process group %d" % child.pid, file=sys.stderr, flush=True)
     timed_out = False
     last_note = t0
@@ -212,10 +216,7 @@ def self_launch(args):
                 except subprocess.TimeoutExpired:
                     continue
             break
-    try:
-        l_out, l_err = child.communicate(timeout=5.0)
-    except subprocess.TimeoutExpired:
-        l_out, l_err = "", ""
+    l_out, l_err = "\n".join(_tail(l_out_path, 1000)), "\n".join(_tail(l_err_path, 200))
     logs = _rank_logs(log_dir)
     line = None
     for ln in _tail(logs.get((0, "stdout"), ""), 1000) + (l_out or "").splitlines():
@@ -341,16 +342,24 @@ def main():
     def say(msg):
         print("bench.py[rank %d/%d pid %d] %s" % (rank, world, os.getpid(), msg), file=sys.stderr, flush=True)
 
+    def watchdog(seconds):
+        """(Re-)arm this rank's watchdog for the phase that starts now; 0 / single-rank runs: off."""
+        if world > 1 and args.rank_timeout > 0:
+            import faulthandler
+            faulthandler.cancel_dump_traceback_later()
+            if seconds > 0:
+                faulthandler.dump_traceback_later(seconds, exit=True, file=sys.stderr)
+
     if world > 1:
         os.environ.setdefault("NCCL_DEBUG", "WARN")
         say("started: LOCAL_RANK %s, device ordinal %d, MASTER %s:%s" % (os.environ.get("LOCAL_RANK"), 0 if args.rehearse_on_device0 else local_rank,
             os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")))
-        if args.rank_timeout > 0:
-            # a stalled rendezvous / collective: this rank reports where it stands and exits by itself (the watchdog thread only writes
-            # and calls _exit: it never touches the GPU, and the rank is not restarted)
-            import faulthandler
-            faulthandler.dump_traceback_later(args.rank_timeout, exit=True, file=sys.stderr)
-        if os.environ.get("PTAMD_BENCH_TEST_STALL"):   # tests/test_multi_gpu_gloo.py: a rank that never comes back
+        # a stalled rendezvous / collective: this rank reports where it stands and exits by itself (the watchdog thread only writes
+        # and calls _exit: it never touches the GPU, and the rank is not restarted).  It bounds one PHASE at a time (rendezvous, set-up +
+        # warm-up, then the timed / kernel passes with an allowance derived from the measured warm-up step), not the run as a whole:
+        # a legitimately long job (--strong, many steps) re-arms it as it goes.
+        watchdog(args.rank_timeout)
+        if args.test_stall_after_start:   # (hidden test-only flag: what a stalled rendezvous looks like from outside)
             time.sleep(1e6)
 
     import numpy as np  # noqa: F401
@@ -379,7 +388,9 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),  # nccl == RCCL on ROCm
                                     timeout=datetime.timedelta(seconds=180))
         say("process group up: backend %s, %.1f s" % (dist.get_backend(), time.perf_counter() - t_pg))
-    if not torch.cuda.is_available():
+        watchdog(args.rank_timeout)   # the next phase: scene, BVH, queues, warm-up
+    have_gpu = torch.cuda.is_available()
+    if not have_gpu and not (world > 1 and args.rehearse_on_device0):
         if world > 1:
             say("no HIP device: this rank cannot render (rendezvous was fine)")
         raise SystemExit("bench.py needs a HIP device" if world == 1 else 3)
@@ -392,7 +403,8 @@ def main():
     if S <= 0:
         import ctypes as _C
         plan = abi.QueuePlan()
-        free_b, _tot = torch.cuda.mem_get_info(local_rank)
+        # (a gloo rehearsal on a box WITHOUT a GPU still takes part in the job's one host-side collective before it refuses: tests/test_multi_gpu_gloo.py)
+        free_b, _tot = torch.cuda.mem_get_info(local_rank) if have_gpu else (0, 0)
         if args.inproc and args.devices:  # logical shards that share a device share its memory
             _d = [int(x) for x in args.devices.split(",")]
             free_b //= max(_d.count(x) for x in set(_d))
@@ -406,6 +418,14 @@ def main():
             if int(t.item()) != S:
                 say("planned %d samples in flight, the job runs %d (the smallest plan of all ranks)" % (S, int(t.item())))
             S = int(t.item())
+            say("job batch: %d samples in flight on every rank" % S)
+    if not have_gpu:
+        say("no HIP device: this rank cannot render (rendezvous and the batch-size all-reduce were fine)")
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        watchdog(0)
+        raise SystemExit(3)
     ndev_all = args.gpus if (args.inproc and args.gpus > 1) else world
     strong_spp = 0
     if args.strong:
@@ -480,11 +500,16 @@ def main():
         return el
 
     # ---- warm-up: W untimed steps ----
+    step_s = 0.0
     if Wu > 0:
         start(Wu * S * ndev, first)
+        t_w = time.perf_counter()
         for _ in range(Wu):
             r.render(S * ndev)
         r.wait()
+        step_s = (time.perf_counter() - t_w) / Wu
+    # each remaining pass (instrumented sample, timed, event-timed) gets the base allowance + 4x its expected length
+    pass_allowance = args.rank_timeout + 4.0 * step_s * K
     # ---- instrumented sample (outside the timed region): BVH nodes / triangles fetched per ray ----
     nodes_c = tris_c = nodes_s = tris_s = 0.0
     if not args.pmc_pass:
@@ -495,9 +520,11 @@ def main():
         nodes_s, tris_s = st0.nodes_per_shadow_ray, st0.tris_per_shadow_ray
 
     # ---- the timed region: K steps, per-kernel event timing off ----
+    watchdog(pass_allowance)
     start(total_spp, first)
     r.setProfiling(False)
     elapsed = timed_pass()
+    watchdog(pass_allowance)
     st = r.stats()
     # the batch the library actually traced (it plans again at start, against the memory left after the scene and the accumulator): a step
     # is only "one batch" when that equals S - otherwise say so instead of labelling several batches as one step

@@ -298,3 +298,25 @@ def test_bench_self_launch_runs_two_ranks_on_this_gpu_and_relays_one_json_line()
     assert d["config"]["spp_total"] == 2 * d["config"]["spp_per_gpu"] and d["extra"]["paths"] > 0
     for r in (0, 1):
         assert "[rank %d] bench.py[rank %d/2" % (r, r) in p.stderr and "process group up: backend gloo" in p.stderr and "renderer on device 0" in p.stderr
+
+
+@pytest.mark.gpu
+def test_bench_c4_command_with_four_ranks_on_this_gpu_renders_1024_samples():
+    """BASELINE.json configs[3]'s command line — `bench.py --gpus N --strong --spp 1024` — with as many ranks as this pool allows on one card
+    (four; eight are rehearsed on CPU as far as the job's collective: tests/test_multi_gpu_gloo.py): the MIN-of-plans all-reduce, sample ranges
+    [256 g, 256 g + 256), ONE reduce of the accumulator inside the timed region, ONE JSON line with `spp_total` = 1024 and `scaling` = strong."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--strong", "--spp", "1024", "--rehearse-on-device0", "--workload", "c1",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-kernel-pass", "--launch-timeout", "300"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=400)
+    assert p.returncode == 0, (p.returncode, p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["scaling"] == "strong" and d["config"]["spp_total"] == 1024 and d["config"]["spp_per_gpu"] == 256 and d["config"]["logical_shards"] == 4
+    assert d["extra"]["paths"] == 512 * 512 * 256 and d["extra"]["time_to_image_ms"] > 0
+    assert p.stderr.count("job batch: ") == 4 and p.stderr.count("process group up: backend gloo") == 4

@@ -28,6 +28,14 @@ import oracle_lib
 pytestmark = pytest.mark.gpu
 
 
+def _group_partition(spp, members):
+    import ctypes as C
+    lib = abi.load_library()
+    first, count = (C.c_uint64 * members)(), (C.c_uint64 * members)()
+    abi.check(lib, lib.pt_group_partition(spp, members, abi.FLAG_MULTISCATTER_GGX, 1, first, count, None, None))
+    return list(first), list(count), None, None
+
+
 def _same_bits_or_both_nan(a, b):
     a, b = np.asarray(a), np.asarray(b)
     return bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
@@ -147,3 +155,61 @@ def test_c5_as_the_driver_times_it_equals_the_oracle(gpu_renderer, tmp_path):
     sc = export_gltf.atrium_through_ingestion(str(tmp_path))
     S, n, dt = _full_size_case(gpu_renderer, sc, W, H, B, spp_expected=46, counters_spp=1)
     print("C5 full size: %d samples in flight, %d probe pixels bit-identical, %.1f s" % (S, n, dt))
+
+
+def test_c4_eight_members_of_128_samples_equal_the_oracle(gpu_renderer):
+    """BASELINE.json configs[3] (C4) at its stated size, as far as one GPU can show it: the C3 scene, 1920x1080, 8 bounces, 1024 spp dealt as
+    8 x 128 — member g renders frameIdx in [128 g, 128 g + 128) (`pt_group_partition`; the reference's only seed is frameIdx,
+    samplers.metal:154-156) into a private running mean, ONE reduction at the end.
+      * every member's PRIVATE mean — one renderer with first_sample = 128 g, incl. g = 7 whose range starts 896 deep in the Halton index —
+        equals the oracle's mean over that range BIT FOR BIT on the probe pixels;
+      * the device group `Renderer(devices=[0] * 8)` (eight logical members: own threads, streams, scene copies, BVHs, queues; the merge path
+        of multi_device.hip minus RCCL) produces, bit for bit, the fp32 fold of those private means in member order times 1/8 (what
+        `ncclAllReduce(sum)` + scale computes up to its own summation order) — the WHOLE image;
+      * and that merged image equals the oracle's 1024-sample running mean to 2e-6 relative (summation order only)."""
+    from platinum_amd import Renderer
+    t_start = time.perf_counter()
+    factory, W, H, _spp, B = scenes.CONFIGS["c3"]
+    N, S = 8, 128
+    scene = factory()
+    first, count, _, _ = _group_partition(N * S, N)
+    assert count == [S] * N and first == [S * g for g in range(N)]
+    r = gpu_renderer
+    r.selectKernel(abi.INTEGRATOR_MIS)
+    r.startRender(scene, (W, H), 1, max_bounces=B)
+    ids = r.tracePrimary(0)["instance"]
+    xy = _probe_pixels(W, H, ids, n_random=256)
+    o = oracle_lib.OracleScene(scene, make_params(W, H, N * S, B))
+    fold = None
+    for g in range(N):
+        r.startRender(scene, (W, H), S, max_bounces=B, first_sample=first[g])   # the library's own batch, as a rank of bench.py --strong renders it
+        r.render(0)
+        r.wait()
+        st = r.stats()
+        assert st.paths == W * H * S
+        a = r.readbackAccumulator()
+        ref = o.render_pixels(xy, first[g], S)
+        got = a[xy[:, 1], xy[:, 0]]
+        bad = ~((got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))).all(axis=1)
+        assert not bad.any(), "member %d, pixels %s: HIP %s oracle %s" % (g, xy[bad][:4].tolist(), got[bad][:4].tolist(), ref[bad][:4].tolist())
+        fold = a[..., :3].copy() if fold is None else fold + a[..., :3]     # k_weighted_add: o += 1.0f * a, member order, fp32
+    fold *= np.float32(1.0 / N)
+    grp = Renderer(devices=[0] * N)
+    try:
+        grp.startRender(scene, (W, H), N * S, max_bounces=B, samples_in_flight=32)   # (8 x 32 in flight = 8 x 13 GB; the image does not depend on the batching)
+        grp.render(0)
+        grp.wait()
+        assert grp.renderProgress() == (N * S, N * S)
+        stg = grp.stats()
+        assert stg.paths == W * H * N * S
+        merged = grp.readbackAccumulator()
+    finally:
+        grp.close()
+    assert (merged[..., 3] == 1).all()
+    assert _same_bits_or_both_nan(merged[..., :3], fold), "the merge is not the fold of the members' private means"
+    ref = o.render_pixels(xy, 0, N * S)
+    got = merged[xy[:, 1], xy[:, 0]]
+    np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=2e-6, atol=1e-7)
+    o.close()
+    print("C4 full size: 8 members x 128 samples, %d probe pixels: private means bit-identical, merge == fold, vs 1024-sample oracle mean <= 2e-6; %.1f s"
+          % (len(xy), time.perf_counter() - t_start))

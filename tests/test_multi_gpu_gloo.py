@@ -65,7 +65,7 @@ def test_self_launch_of_a_stalled_job_times_out_and_reports_every_rank():
     which never touched the GPU — ends the child process group at its wall limit, prints each rank's last lines and exits 124."""
     import time
     t0 = time.time()
-    p = _bench("--gpus", "2", "--launch-timeout", "12", "--no-cpu-baseline", env={"PTAMD_BENCH_TEST_STALL": "1"})
+    p = _bench("--gpus", "2", "--launch-timeout", "12", "--no-cpu-baseline", "--test-stall-after-start")
     assert p.returncode == 124, (p.returncode, p.stderr[-2000:])
     assert time.time() - t0 < 90
     assert "TIMEOUT" in p.stderr and '"metric"' not in p.stdout
@@ -91,11 +91,29 @@ def test_self_launch_rendezvous_works_and_ranks_refuse_without_a_gpu():
     assert "no HIP device" in p.stderr and "no result line" in p.stderr
 
 
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the refusal path of a box WITHOUT a GPU")
+def test_eight_rank_c4_launch_reaches_the_job_collective_on_cpu():
+    """BASELINE.json configs[3] as the driver would start it on an 8-GPU node — `bench.py --gpus 8 --strong --spp 1024` — rehearsed with EIGHT
+    fresh ranks over gloo on this CPU-only box: the launcher brings all eight up, every rank joins the process group,
+    takes part in the job's one host-side collective (the MIN over the ranks' planned batch sizes: every rank must trace the same batch for the
+    sample ranges [g K S, (g + 1) K S) to tile the render) and only THEN refuses for want of a HIP device — exit 3 on every rank, relayed, no
+    result line, nothing left behind.  The rendering half of the same command runs on the one-GPU box (tests/test_device_group.py)."""
+    p = _bench("--gpus", "8", "--strong", "--spp", "1024", "--workload", "c1", "--rehearse-on-device0", "--launch-timeout", "200", "--no-cpu-baseline",
+               env={"OMP_NUM_THREADS": "1"}, timeout=300)
+    assert p.returncode not in (0, 124), (p.returncode, p.stderr[-3000:])
+    assert '"metric"' not in p.stdout
+    assert p.stderr.count("process group up: backend gloo") == 8, p.stderr[-4000:]
+    for r in range(8):
+        assert "bench.py[rank %d/8" % r in p.stderr
+    assert p.stderr.count("job batch: ") == 8 and len(set(ln.split("job batch: ")[1] for ln in p.stderr.splitlines() if "job batch: " in ln)) == 1
+    assert p.stderr.count("rendezvous and the batch-size all-reduce were fine") == 8
+
+
 def test_a_rank_watchdog_ends_a_stalled_rank_with_its_stack():
     """Under the DRIVER's own launcher there is no parent of ours: a rank that stalls dumps its Python stacks and exits by itself."""
     import subprocess
-    e = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999", PTAMD_BENCH_TEST_STALL="1")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rank-timeout", "3"], env=e, stdout=subprocess.PIPE,
+    e = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rank-timeout", "3", "--test-stall-after-start"], env=e, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=60)
     assert p.returncode != 0
     assert "started: LOCAL_RANK 0" in p.stderr and "Timeout (0:00:03)!" in p.stderr and "bench.py" in p.stderr
