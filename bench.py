@@ -57,6 +57,7 @@ WORKLOADS = {
     "c1": "C1 Cornell box 512x512",
     "c2": "C2 Cornell box + GGX dielectric sphere (6144 tris), 1920x1080",
     "c3": "C3 1.04M-triangle instanced sphere field, 1920x1080",
+    "c3xl": "context (not a BASELINE config): the C3 field with 128x128 instances = 16.6M triangles, structure > the 256 MB Infinity Cache, 1920x1080",
     "c5": "C5 Sponza-class atrium (258k tris, JPEG/PNG textures, cut-outs, 4096x2048 EXR environment) imported from .glb + .exr, 3840x2160",
 }
 

@@ -744,5 +744,9 @@ CONFIGS = {
     "c1": (lambda: cornell_scene("bench"), 512, 512, 64, 4),
     "c2": (cornell_sphere_scene, 1920, 1080, 256, 8),
     "c3": (field_scene, 1920, 1080, 256, 8),
+    # context workload, not a BASELINE.json config: the same field with 128 x 128 instances = 16.6 M triangles — a structure
+    # (~0.8 GB) that exceeds the 256 MB Infinity Cache, i.e. the regime in which HBM really is what the traversal kernels fetch from.  (The
+    # spheres keep their size while their spacing drops to 0.5: they interpenetrate, most triangles lie inside a neighbour.)
+    "c3xl": (lambda: field_scene(128), 1920, 1080, 256, 8),
     "c5": (atrium_scene, 3840, 2160, 512, 12),
 }

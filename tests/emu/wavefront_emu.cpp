@@ -900,6 +900,187 @@ void emu_origin_sort_probe(void* h, uint32_t tile_x, uint32_t tile_y, uint32_t n
   const double sorted = distinct(order);
   out[0] = (double)rays.size(); out[1] = (double)((rays.size() + 63) / 64); out[2] = total; out[3] = arrival; out[4] = sorted;
 }
+// ---- experiment (emu_l2_probe, r6): would SCENE-SPACE ray queues keep the closest-hit kernel's BVH lines inside the XCDs' L2s?
+// The rays entering bounce `bounce` of a window of the image (tiles [s0, s0 + T) of each of the 4 segment bands, `ns` samples: what the chunk
+// tables list consecutively today) are traced on the product's 6-wide tree with every 64-byte line (node or leaf slot) they fetch recorded, then
+// REPLAYED through a model of the chip's eight L2s — 4 MB each, 64-byte lines (the counters' miss = one 64-byte fetch: 116 B / 1.93 per ray,
+// profiles/r05_pmc_c3.json), 16-way LRU — fed by 768 resident waves per XCD (32 CUs x 4 SIMDs x 6 waves), every wave stepping its 64 rays one
+// line per tick, all waves of the chip round-robin, chunks claimed 8 at a time:
+//   mode 0  today: ONE cursor over the chunk list in segment order (whichever wave asks next gets the run: XCDs interleave)
+//   mode 1  rays sorted by the Morton cell of their ORIGIN (10 bits per axis over the origins' bounds), cut into 8 contiguous ranges, one per
+//           XCD, each XCD's waves claiming from their own cursor — the scheduler DESIGN section 7 names
+//   mode 2  the sorted list behind ONE cursor (what the sort alone buys, without the partition)
+// At bounce 1 the window's ray density per cell equals the full frame's (origins = the window's own primary hits); at bounce >= 2 origins
+// scatter and the window's density is LOWER than the full frame's: modes 1 / 2 are then pessimistic (emu_l2_probe_dense covers that case).
+// out[mode][6] = {rays counted (chunks claimed after the first fifth of the list), BVH line touches, BVH misses, queue lines streamed,
+//                wave-steps, wave-steps in which at least one lane missed (a wave-step waits for its slowest lane)}
+struct ProbeRay { float o[3]; uint32_t first, count; };
+struct L2Sim {
+  static constexpr uint32_t kWays = 16;
+  uint32_t sets;
+  std::vector<uint32_t> tag, stamp;
+  uint32_t clock = 1;
+  explicit L2Sim(uint32_t bytes) : sets(bytes / 64u / kWays), tag((size_t)sets * kWays, 0xffffffffu), stamp((size_t)sets * kWays, 0u) {}
+  bool touch(uint32_t line) {   // true = hit
+    const uint32_t s = (line * 2654435761u >> 7) % sets;   // (the hardware hashes addresses over channels / sets; a plain modulo would alias the two arrays)
+    uint32_t* t = &tag[(size_t)s * kWays]; uint32_t* st = &stamp[(size_t)s * kWays];
+    uint32_t victim = 0;
+    for (uint32_t w = 0; w < kWays; w++) {
+      if (t[w] == line) { st[w] = clock++; return true; }
+      if (st[w] < st[victim]) victim = w;
+    }
+    t[victim] = line; st[victim] = clock++;
+    return false;
+  }
+};
+static void gen_tile_rays(const Emu* e, uint32_t tile_x, uint32_t tile_y, uint32_t ns, uint32_t bounce, std::vector<ProbeRay>* rays, std::vector<uint32_t>* lines,
+                          uint32_t* lds, uint32_t* spill, uint32_t* pend) {
+  const DeviceScene& S = e->S;
+  std::vector<uint32_t> tmp;
+  for (uint32_t pl = 0; pl < 64; pl++)
+    for (uint32_t smp = 0; smp < ns; smp++) {
+      const uint32_t x = tile_x * 8 + (pl & 7), y = tile_y * 8 + (pl >> 3);
+      if (x >= S.width || y >= S.height) continue;
+      RayGenOut rg = stage_raygen(S, x, y, smp);
+      vec3 o = rg.o, d = rg.d, att = v3(1.0f);
+      float lastPdf = 0.0f; bool lastSpec = false; uint32_t dim = rg.dim;
+      bool alive = true;
+      for (uint32_t b = 0; b < bounce && alive; b++) {
+        TraversalStack st; st.lds = lds; st.pend = pend; st.lds_stride = 1; st.spill = spill; st.spill_stride = 1;
+        const RayHit hit = traverse<false, false>(S, o, d, 1e-3f, kInf, 0.0f, st, nullptr);
+        if (hit.tri == kInvalidRef) { alive = false; break; }
+        const vec4 qO{o.x, o.y, o.z, lastPdf}, qD{d.x, d.y, d.z, 0.0f};
+        ShadeIn in; in.o = o; in.d = d; in.att = att; in.rayO = &qO; in.rayD = &qD; in.lastSpecular = lastSpec; in.offset = rg.offset;
+        in.dim = dim + 1; in.bounce = b; in.t = hit.t; in.u = hit.u; in.v = hit.v; in.tri = hit.tri;
+        const ShadeOut so = stage_shade(S, in);
+        if (!so.alive) { alive = false; break; }
+        o = so.next_o; d = so.next_d; att = so.next_att; lastPdf = so.next_pdf; lastSpec = so.next_specular; dim = so.dim & kMetaDimMask;
+      }
+      if (!alive) continue;
+      tmp.clear();
+      trace_lines(S, o, d, lds, spill, pend, &tmp);
+      ProbeRay r; r.o[0] = o.x; r.o[1] = o.y; r.o[2] = o.z; r.first = (uint32_t)lines->size(); r.count = (uint32_t)tmp.size();
+      for (uint32_t l : tmp) lines->push_back((l & 0x80000000u) ? S.node_count + (l & 0x7fffffffu) : l);   // one 64-byte line address space: nodes, then slots
+      rays->push_back(r);
+    }
+}
+struct ChunkRef { uint32_t first, count; };   // rays order[first .. first + count)
+static void l2_replay(const std::vector<ProbeRay>& rays, const std::vector<uint32_t>& lines, const std::vector<uint32_t>& order,
+                      const std::vector<std::vector<ChunkRef>>& queues /* 1 (shared) or 8 (one per XCD) */, uint32_t waves_per_xcd, uint32_t l2_bytes,
+                      uint32_t line_space, double out[6]) {
+  struct Wave { uint32_t next_c = 0, end_c = 0, first = 0, count = 0, step = 0, maxlen = 0; bool active = false, counted = false; };
+  std::vector<L2Sim> l2; for (int x = 0; x < 8; x++) l2.emplace_back(l2_bytes);
+  std::vector<std::vector<Wave>> waves(8, std::vector<Wave>(waves_per_xcd));
+  std::vector<uint32_t> cursor(queues.size(), 0);
+  uint32_t stream_line = line_space;   // queue entries: lines nobody has seen before
+  double n_rays = 0, touches = 0, misses = 0, streamed = 0, wave_steps = 0, wave_steps_missing = 0;
+  bool any = true;
+  while (any) {
+    any = false;
+    for (uint32_t w = 0; w < waves_per_xcd; w++)
+      for (int x = 0; x < 8; x++) {
+        Wave& wv = waves[x][w];
+        const size_t q = queues.size() == 1 ? 0 : (size_t)x;
+        if (!wv.active) {
+          if (wv.next_c == wv.end_c) {
+            if (cursor[q] >= queues[q].size()) continue;
+            wv.next_c = cursor[q]; cursor[q] += 8; wv.end_c = std::min<uint32_t>(cursor[q], (uint32_t)queues[q].size());
+          }
+          const ChunkRef c = queues[q][wv.next_c];
+          wv.counted = wv.next_c * 5u >= queues[q].size();
+          wv.next_c++;
+          wv.first = c.first; wv.count = c.count; wv.step = 0; wv.maxlen = 0; wv.active = true;
+          for (uint32_t k = 0; k < c.count; k++) wv.maxlen = std::max(wv.maxlen, rays[order[c.first + k]].count);
+          // the chunk's rays: rayO + rayD = 32 B each = 32 lines per 64 rays, streamed in (misses by construction); hit records (16 lines) are written
+          for (uint32_t k = 0; k < (c.count * 32u + 63u) / 64u + (c.count * 16u + 63u) / 64u; k++) (void)l2[x].touch(stream_line++);
+          if (wv.counted) { n_rays += c.count; streamed += (c.count * 48.0) / 64.0; }
+        }
+        bool step_missed = false;
+        for (uint32_t k = 0; k < wv.count; k++) {
+          const ProbeRay& r = rays[order[wv.first + k]];
+          if (wv.step < r.count) {
+            const bool hit = l2[x].touch(lines[r.first + wv.step]);
+            if (wv.counted) { touches += 1; misses += hit ? 0 : 1; }
+            step_missed |= !hit;
+          }
+        }
+        if (wv.counted) { wave_steps += 1; wave_steps_missing += step_missed ? 1 : 0; }   // a wave-step waits for its slowest lane
+        wv.step++;
+        if (wv.step >= wv.maxlen) wv.active = false;
+        any = true;
+      }
+  }
+  out[0] = n_rays; out[1] = touches; out[2] = misses; out[3] = streamed; out[4] = wave_steps; out[5] = wave_steps_missing;
+}
+static void l2_three_modes(const std::vector<ProbeRay>& rays, const std::vector<uint32_t>& lines, const std::vector<uint32_t>& arrival_order,
+                           const std::vector<uint32_t>& seg_end /* arrival_order positions where a segment ends */, uint32_t line_space,
+                           uint32_t waves_per_xcd, uint32_t l2_bytes, uint32_t cell_bits, double out[18]) {
+  auto cut = [](uint32_t first, uint32_t end, std::vector<ChunkRef>* q) { for (uint32_t c = first; c < end; c += 64) q->push_back({c, std::min(64u, end - c)}); };
+  // mode 0: segment order, chunks never straddle segments
+  {
+    std::vector<std::vector<ChunkRef>> q(1);
+    uint32_t at = 0;
+    for (uint32_t e_ : seg_end) { cut(at, e_, &q[0]); at = e_; }
+    l2_replay(rays, lines, arrival_order, q, waves_per_xcd, l2_bytes, line_space, &out[0]);
+  }
+  // origin cells
+  float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+  for (auto& r : rays) for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], r.o[a]); hi[a] = fmaxf(hi[a], r.o[a]); }
+  const float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), fmaxf(hi[2] - lo[2], 1e-20f));
+  const float cells = (float)(1u << cell_bits);
+  std::vector<uint64_t> key(rays.size());
+  for (size_t i = 0; i < rays.size(); i++) {
+    uint64_t c[3];
+    for (int a = 0; a < 3; a++) c[a] = (uint64_t)fminf(cells - 1.0f, (rays[i].o[a] - lo[a]) / ext * cells);
+    key[i] = expand21(c[0]) << 2 | expand21(c[1]) << 1 | expand21(c[2]);
+  }
+  std::vector<uint32_t> sorted(arrival_order);
+  std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+  {
+    std::vector<std::vector<ChunkRef>> q(8);
+    const uint32_t n = (uint32_t)sorted.size();
+    for (uint32_t x = 0; x < 8; x++) cut((uint32_t)((uint64_t)n * x / 8), (uint32_t)((uint64_t)n * (x + 1) / 8), &q[x]);
+    l2_replay(rays, lines, sorted, q, waves_per_xcd, l2_bytes, line_space, &out[6]);
+  }
+  {
+    std::vector<std::vector<ChunkRef>> q(1);
+    cut(0, (uint32_t)sorted.size(), &q[0]);
+    l2_replay(rays, lines, sorted, q, waves_per_xcd, l2_bytes, line_space, &out[12]);
+  }
+}
+void emu_l2_probe(void* h, uint32_t bounce, uint32_t ns, uint32_t s0, uint32_t T, uint32_t waves_per_xcd, uint32_t l2_bytes, uint32_t cell_bits,
+                  uint32_t threads, double out[18]) {
+  Emu* e = (Emu*)h;
+  const DeviceScene& S = e->S;
+  for (int i = 0; i < 18; i++) out[i] = 0;
+  if (!S.wide6) return;
+  const uint32_t tilesX = (S.width + 7) / 8, tilesY = (S.height + 7) / 8, tiles = tilesX * tilesY, per_band = tiles / 4;
+  // today's table order: segment sg = 4 * idx + band  ->  tile band * per_band + idx (kernels.hip segment_first_tile)
+  std::vector<uint32_t> seg_tile;
+  for (uint32_t idx = s0; idx < s0 + T && idx < per_band; idx++) for (uint32_t band = 0; band < 4; band++) seg_tile.push_back(band * per_band + idx);
+  std::vector<std::vector<ProbeRay>> tr(seg_tile.size());
+  std::vector<std::vector<uint32_t>> tl(seg_tile.size());
+  std::atomic<uint32_t> cursor{0};
+  auto worker = [&]() {
+    std::vector<uint32_t> lds(std::max(kLdsStack, kLdsStack6) + 1), spill(kSpillStack), pend(std::max(kPendLeaves, kPendLeaves6) + 1);
+    for (;;) {
+      const uint32_t i = cursor.fetch_add(1);
+      if (i >= seg_tile.size()) return;
+      gen_tile_rays(e, seg_tile[i] % tilesX, seg_tile[i] / tilesX, ns, bounce, &tr[i], &tl[i], lds.data(), spill.data(), pend.data());
+    }
+  };
+  { std::vector<std::thread> pool; for (uint32_t i = 1; i < std::max(1u, threads); i++) pool.emplace_back(worker); worker(); for (auto& t : pool) t.join(); }
+  std::vector<ProbeRay> rays; std::vector<uint32_t> lines, order, seg_end;
+  for (size_t i = 0; i < seg_tile.size(); i++) {
+    const uint32_t base = (uint32_t)lines.size();
+    for (auto r : tr[i]) { r.first += base; order.push_back((uint32_t)rays.size()); rays.push_back(r); }
+    lines.insert(lines.end(), tl[i].begin(), tl[i].end());
+    seg_end.push_back((uint32_t)rays.size());
+    std::vector<ProbeRay>().swap(tr[i]); std::vector<uint32_t>().swap(tl[i]);
+  }
+  if (rays.empty()) return;
+  l2_three_modes(rays, lines, order, seg_end, S.node_count + S.slot_count, waves_per_xcd, l2_bytes, cell_bits, out);
+}
 void emu_get_wide(double out[26]) {
   int i = 0;
   const double r = g_wide.rays ? (double)g_wide.rays : 1.0;

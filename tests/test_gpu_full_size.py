@@ -166,7 +166,10 @@ def test_c4_eight_members_of_128_samples_equal_the_oracle(gpu_renderer):
       * the device group `Renderer(devices=[0] * 8)` (eight logical members: own threads, streams, scene copies, BVHs, queues; the merge path
         of multi_device.hip minus RCCL) produces, bit for bit, the fp32 fold of those private means in member order times 1/8 (what
         `ncclAllReduce(sum)` + scale computes up to its own summation order) — the WHOLE image;
-      * and that merged image equals the oracle's 1024-sample running mean to 2e-6 relative (summation order only)."""
+      * and that merged image equals the oracle's 1024-sample running mean to 1e-5 relative.  That tolerance is summation order only, and it is
+        the SEQUENTIAL mean that carries most of it: kernel.metal:672-684 rounds twice per sample, so 1024 samples leave a random walk of
+        ~sqrt(2048) x 6e-8 = 2.7e-6 (observed maximum over 2 172 values: 3.4e-6), the eight 128-sample means a third of that.  (96 x 64 x <= 9
+        samples hold SURVEY section 8c's 2e-6: tests/test_device_group.py.)"""
     from platinum_amd import Renderer
     t_start = time.perf_counter()
     factory, W, H, _spp, B = scenes.CONFIGS["c3"]
@@ -209,7 +212,40 @@ def test_c4_eight_members_of_128_samples_equal_the_oracle(gpu_renderer):
     assert _same_bits_or_both_nan(merged[..., :3], fold), "the merge is not the fold of the members' private means"
     ref = o.render_pixels(xy, 0, N * S)
     got = merged[xy[:, 1], xy[:, 0]]
-    np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=1e-5, atol=1e-7)
+    worst = float(np.max(np.abs(got[:, :3] - ref[:, :3]) / np.maximum(np.abs(ref[:, :3]), 1e-3)))
     o.close()
-    print("C4 full size: 8 members x 128 samples, %d probe pixels: private means bit-identical, merge == fold, vs 1024-sample oracle mean <= 2e-6; %.1f s"
-          % (len(xy), time.perf_counter() - t_start))
+    print("C4 full size: 8 members x 128 samples, %d probe pixels: private means bit-identical, merge == fold of the private means (whole image), "
+          "vs 1024-sample sequential oracle mean: max relative difference %.2g; %.1f s" % (len(xy), worst, time.perf_counter() - t_start))
+
+
+def test_c3xl_a_structure_beyond_the_infinity_cache_equals_the_oracle(gpu_renderer):
+    """`bench.py --workload c3xl` (context): the field with 128 x 128 instances = 16.6 M triangles — leaf slots + 6-wide nodes +
+    shade records ~ 1.3 GB, five times the 256 MB Infinity Cache, where C3's 47 MB structure sits inside it.  Same code path as C3 (one BVH over
+    the flattened triangles, built on the GPU); what changes is where the lines come from, and the index ranges (8.5 M leaf slots, 27 bits of
+    triangle index in the hit word).  At a resolution the oracle (its own median-split tree over the same 16.6 M triangles: ~35 s to build) walks
+    in seconds: the whole image, ray counters and primary hits bit-identical."""
+    t_start = time.perf_counter()
+    factory, _W, _H, _spp, B = scenes.CONFIGS["c3xl"]
+    W, H, S = 480, 270, 8
+    scene = factory()
+    r = gpu_renderer
+    r.selectKernel(abi.INTEGRATOR_MIS)
+    r.startRender(scene, (W, H), S, max_bounces=B)
+    prim = r.tracePrimary(0)
+    r.render(0)
+    r.wait()
+    st = r.stats()
+    assert st.triangles == 12 + 128 * 128 * 1012
+    acc = r.readbackAccumulator()
+    o = oracle_lib.OracleScene(scene, make_params(W, H, S, B))
+    ref = o.render(0, S)
+    so = o.stats()
+    assert (st.paths, st.closest_rays, st.shadow_rays, st.shaded_hits) == (so.paths, so.closest_rays, so.shadow_rays, so.shaded_hits)
+    oprim = o.trace_primary(0)
+    for f in ("instance", "primitive"):
+        assert np.array_equal(prim[f], oprim[f])
+    assert np.array_equal(prim["t"].view(np.uint32), oprim["t"].view(np.uint32))
+    assert _same_bits_or_both_nan(acc, ref)
+    o.close()
+    print("C3XL: %d triangles, %d BVH nodes, %dx%d x %d samples bit-identical to the oracle, %.1f s" % (st.triangles, st.bvh_nodes, W, H, S, time.perf_counter() - t_start))
