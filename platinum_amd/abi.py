@@ -285,34 +285,40 @@ def _torch_bundled_hip():
 
 
 def _elf_dynamic_strings(path, tag):
-    """DT_SONAME (tag 14) / DT_NEEDED (tag 1) strings of an ELF64 little-endian shared object, read without any tool; [] on any surprise."""
+    """DT_SONAME (tag 14) / DT_NEEDED (tag 1) strings of an ELF64 little-endian shared object, read without any tool; [] on any surprise.
+    Only the ELF header, the section headers, .dynamic and .dynstr are read (seek): libamdhip64.so is tens of megabytes."""
     import struct
     try:
         with open(path, "rb") as f:
-            data = f.read()
-        if data[:4] != b"\x7fELF" or data[4] != 2 or data[5] != 1:
-            return []
-        shoff, = struct.unpack_from("<Q", data, 0x28)
-        shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
-        secs = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
-        out = []
-        for sec in secs:
-            if sec[1] != 6:      # SHT_DYNAMIC
-                continue
-            stroff = secs[sec[6]][4]   # sh_link -> .dynstr
-            for off in range(sec[4], sec[4] + sec[5], 16):
-                t, v = struct.unpack_from("<qQ", data, off)
-                if t == 0:
-                    break
-                if t == tag:
-                    end = data.index(b"\0", stroff + v)
-                    out.append(data[stroff + v:end].decode())
-        return out
+            hdr = f.read(0x40)
+            if hdr[:4] != b"\x7fELF" or hdr[4] != 2 or hdr[5] != 1:
+                return []
+            shoff, = struct.unpack_from("<Q", hdr, 0x28)
+            shentsize, shnum = struct.unpack_from("<HH", hdr, 0x3A)
+            if shentsize < 64 or shnum == 0 or shnum > 4096:
+                return []
+            f.seek(shoff)
+            sh = f.read(shentsize * shnum)
+            secs = [struct.unpack_from("<IIQQQQIIQQ", sh, i * shentsize) for i in range(shnum)]
+            out = []
+            for sec in secs:
+                if sec[1] != 6:      # SHT_DYNAMIC
+                    continue
+                strsec = secs[sec[6]]   # sh_link -> .dynstr
+                f.seek(sec[4]); dyn = f.read(sec[5])
+                f.seek(strsec[4]); strtab = f.read(strsec[5])
+                for off in range(0, len(dyn) - 15, 16):
+                    t, v = struct.unpack_from("<qQ", dyn, off)
+                    if t == 0:
+                        break
+                    if t == tag:
+                        out.append(strtab[v:strtab.index(b"\0", v)].decode())
+            return out
     except Exception:
         return []
 
 
-def _settle_hip_runtime():
+def _settle_hip_runtime(lib_file=None):
     """Make sure the process ends up with ONE HIP runtime whichever of {libptamd.so, torch} arrives first.
 
     Root cause (round 4): torch's wheel bundles libamdhip64.so / libhsa-runtime64.so / librccl.so with the same SONAMEs
@@ -339,7 +345,7 @@ def _settle_hip_runtime():
     # torch wheel built for another ROCm major carries another soname: preloading it would put a runtime into the process that libptamd.so
     # does not bind to, /opt/rocm's would be mapped beside it, and every pt_create would fail with "two GPU runtimes" (ADVICE r4).
     soname = _elf_dynamic_strings(bundled, 14)
-    needed = [n for n in _elf_dynamic_strings(library_path(), 1) if n.startswith("libamdhip64.so")]
+    needed = [n for n in _elf_dynamic_strings(lib_file or library_path(), 1) if n.startswith("libamdhip64.so")]
     if soname and needed and soname[0] not in needed:
         return ("system (torch bundles %s, libptamd.so needs %s: a different ROCm major - not preloaded; do not import torch in this process, "
                 "or build libptamd.so against torch's ROCm)" % (soname[0], needed[0]))
@@ -372,7 +378,7 @@ def load_library(path=None):
     p = path or os.environ.get("PTAMD_LIB", LIB_PATH)
     if not os.path.exists(p):
         raise PtamdError(f"{p} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()')")
-    note = _settle_hip_runtime()
+    note = _settle_hip_runtime(p)   # (the SONAME / DT_NEEDED check reads the library actually being loaded)
     lib = C.CDLL(p)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the export is missing
@@ -384,7 +390,7 @@ def load_library(path=None):
         raise PtamdError("two GPU runtimes are mapped into this process (" + ri.all_mapped.decode() + "): only the one that initialises "
                          "first would see the GPU.  Import torch, or platinum_amd, before anything else that links /opt/rocm's libamdhip64; "
                          "in a process that never uses torch, $PTAMD_HIP_RUNTIME=system keeps /opt/rocm's runtime alone (how the HIP runtime was settled: "
-                         + str(_runtime_note) + ")")
+                         + str(note) + ")")
     if path is None:
         _lib = lib
         _runtime_note = note

@@ -36,6 +36,8 @@ void launch_raygen(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState
 void launch_chunk_tables(hipStream_t s, Segments seg, uint32_t cur, BatchCounters* ctr, uint32_t bounce_closest,
                          uint32_t bounce_shadow, bool do_shadow);
 uint32_t seg_group_chunks();
+size_t lbuf_index_host(uint32_t tile, uint32_t s, uint32_t nsamples, uint32_t lane);   // kernels.hip lbuf_index, for the host (debug read-back)
+size_t lbuf_sample_stride_host();
 uint32_t trace_block_threads(bool two_level);
 uint32_t trace_blocks_per_cu_two_level();  // 256 (7 blocks per CU) for one BVH, 1024 (one block per CU) for the two-level structure
 void launch_trace_closest(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState st, vec4* hit, Segments seg, uint32_t cur,

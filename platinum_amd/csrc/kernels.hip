@@ -79,9 +79,6 @@ static_assert(PT_SEG_GROUP == kSegGroupChunks, "queue_plan.h sizes the queue arr
 // while plenty of work is left, then 4, 2, 1 towards the end of the list so that the last waves finish together
 // (a fixed 8 costs C3 3 % in the tail; guided, C2 closest-hit went from 36.2 to 23.0 ms per step, shadow from 26.0 to 15.4).
 constexpr uint32_t kClaimMax = 8;
-#ifndef PT_XCD_CLAIMS
-#define PT_XCD_CLAIMS 0
-#endif
 
 struct ChunkClaims {
   const uint32_t* __restrict__ table;   // [total] (k << 16) | s  for every non-empty chunk, segment-major
@@ -96,15 +93,7 @@ struct ChunkClaims {
     next_c = end_c = 0;
     nwaves_grid = gridDim.x * (blockDim.x >> 6);
     claim_k = guided(total);
-#if PT_XCD_CLAIMS
-    slice = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID[3:0]: the XCD this wave runs on
-    slices_done = 0;
-#endif
   }
-#if PT_XCD_CLAIMS
-  uint32_t* xcd_cursors = nullptr;
-  uint32_t slice = 0, slices_done = 0;
-#endif
   __device__ __forceinline__ uint32_t guided(uint32_t remaining) const {
     return remaining > 32u * nwaves_grid ? kClaimMax : remaining > 8u * nwaves_grid ? 4u : remaining > 2u * nwaves_grid ? 2u : 1u;
   }
@@ -122,22 +111,6 @@ struct ChunkClaims {
       if (pool_next == pool_end) {
         if (exhausted) return got;
         if (next_c == end_c) {
-#if PT_XCD_CLAIMS
-          // (r6 experiment) the list is cut into 8 contiguous slices, one per XCD; a wave claims from its own XCD's slice first and helps the following
-          // ones once that is empty — the rays in flight on an XCD then come from ONE part of the list (= of the image; = of the scene for bounces 0 / 1)
-          for (;;) {
-            if (slices_done == 8u) { exhausted = true; return got; }
-            const uint32_t s0 = (uint32_t)(((unsigned long long)total * slice) >> 3), s1 = (uint32_t)(((unsigned long long)total * (slice + 1u)) >> 3);
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&xcd_cursors[slice], claim_k);
-            base = __builtin_amdgcn_readfirstlane(base) + s0;
-            if (base >= s1) { slice = (slice + 1u) & 7u; slices_done++; claim_k = 1u; continue; }
-            next_c = base;
-            end_c = base + claim_k < s1 ? base + claim_k : s1;
-            claim_k = guided((s1 - end_c) * 8u);
-            break;
-          }
-#else
           uint32_t base = 0;
           if (lane == 0) base = atomicAdd(cursor, claim_k);
           base = __builtin_amdgcn_readfirstlane(base);
@@ -145,7 +118,6 @@ struct ChunkClaims {
           next_c = base;
           end_c = base + claim_k < total ? base + claim_k : total;
           claim_k = guided(total - end_c);
-#endif
         }
         const uint32_t e = table[next_c++];
         const uint32_t sg = e & 0xffffu, k = e >> 16;
@@ -241,6 +213,11 @@ __device__ __forceinline__ uint32_t lbuf_index(uint32_t tile, uint32_t s, uint32
 #endif
 }
 constexpr uint32_t kLbufSampleStride = PT_PIXEL_MAJOR ? 1u : 64u;  // distance between successive samples of one pixel
+// (host mirrors for the debug build's $PTAMD_DEBUG_PIXEL read-back: the layout this translation unit was compiled with)
+size_t lbuf_index_host(uint32_t tile, uint32_t s, uint32_t nsamples, uint32_t lane) {
+  return PT_PIXEL_MAJOR ? ((size_t)tile * 64u + lane) * nsamples + s : ((size_t)tile * nsamples + s) * 64u + lane;
+}
+size_t lbuf_sample_stride_host() { return kLbufSampleStride; }
 __device__ __forceinline__ uint32_t lbuf_index_of_pixel(uint32_t p, uint32_t W, uint32_t s, uint32_t nsamples) {
   const uint32_t y = p / W, x = p - y * W, tilesX = (W + 7u) / 8u;
   return lbuf_index((y >> 3) * tilesX + (x >> 3), s, nsamples, (y & 7u) * 8u + (x & 7u));
@@ -391,9 +368,6 @@ k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments se
   const uint32_t lane = wave_lane();
   ChunkClaims src;
   src.init(seg.table_closest, ctr->chunks_closest[bounce], seg.active[cur], &ctr->work_closest[bounce], seg, lane);
-#if PT_XCD_CLAIMS
-  src.xcd_cursors = &ctr->xcd_closest[bounce][0];
-#endif
   TraversalStack stack;
   stack.lds = &lds_stack[0][threadIdx.x];
   stack.pend = &lds_pend[0][threadIdx.x];
@@ -711,9 +685,6 @@ k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments 
   const uint32_t lane = wave_lane();
   ChunkClaims src;
   src.init(seg.table_shadow, ctr->chunks_shadow[bounce], seg.shadow, &ctr->work_shadow[bounce], seg, lane);
-#if PT_XCD_CLAIMS
-  src.xcd_cursors = &ctr->xcd_shadow[bounce][0];
-#endif
   TraversalStack stack;
   stack.lds = &lds_stack[0][threadIdx.x];
   stack.pend = &lds_pend[0][threadIdx.x];

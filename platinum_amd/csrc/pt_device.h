@@ -263,7 +263,6 @@ struct BatchCounters {
   uint32_t nonfinite;     // samples with NaN/inf radiance seen by k_accumulate
   uint32_t _pad[2];
   unsigned long long nodes_closest, tris_closest, nodes_shadow, tris_shadow;  // instrumented runs only
-  uint32_t xcd_closest[64][8], xcd_shadow[64][8];   // PT_XCD_CLAIMS builds only: one claim cursor per XCD slice of the chunk lists
 };
 
 struct Totals {  // running totals since pt_start_render (folded from BatchCounters after each batch)

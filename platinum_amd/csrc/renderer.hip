@@ -513,6 +513,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   r->accumulated = 0;
   r->launched = 0;
   r->batches = 0;
+  r->last_batch_ns = 0;   // Lbuf holds nothing of THIS render yet
   r->batch_done_valid = false;
   r->total = p->spp;
   r->started = true;
@@ -581,21 +582,26 @@ int dev_wait(pt_renderer* r) {
       fprintf(stderr, "\n");
     }
   }
+#ifdef PT_DEBUG_PID   // debug build only (tools/build_variant.sh dbg -DPT_DEBUG_PID), like $PTAMD_DEBUG_RAY: nothing of it ships in libptamd.so
   if (r->started && r->last_batch_ns) {
-    if (const char* e = getenv("PTAMD_DEBUG_PIXEL")) {  // analysis aid: "x,y" -> the per-sample radiance of that pixel in the LAST batch (Lbuf is [tile][pixel][sample])
+    if (const char* e = getenv("PTAMD_DEBUG_PIXEL")) {  // analysis aid: "x,y" -> the per-sample radiance of that pixel in the LAST batch
       uint32_t x = 0, y = 0;
       if (sscanf(e, "%u,%u", &x, &y) == 2 && x < r->S.width && y < r->S.height) {
         const uint32_t tilesX = (r->S.width + 7) / 8, ns = r->last_batch_ns;
+        const uint32_t tile = (y >> 3) * tilesX + (x >> 3), pl = (y & 7) * 8 + (x & 7);
+        const size_t at0 = lbuf_index_host(tile, 0, ns, pl), stride = lbuf_sample_stride_host();   // the layout kernels.hip was compiled with
         std::vector<vec4> v(ns);
-        const size_t at = ((size_t)((y >> 3) * tilesX + (x >> 3)) * 64 + (y & 7) * 8 + (x & 7)) * ns;
-        if (hipMemcpy(v.data(), r->Lbuf.p + at, sizeof(vec4) * ns, hipMemcpyDeviceToHost) == hipSuccess)
-          for (uint32_t k = 0; k < ns; k++) {
-            uint32_t b[3]; memcpy(b, &v[k], 12);
-            fprintf(stderr, "ptamd pixel %u,%u sample %u: %08x %08x %08x  %.9g %.9g %.9g\n", x, y, r->last_batch_first + k, b[0], b[1], b[2], v[k].x, v[k].y, v[k].z);
-          }
+        bool ok = at0 + (size_t)(ns - 1) * stride < r->Lbuf.n;   // (a restart with another size / batch before any new batch: last_batch_ns is reset then, this is the belt)
+        for (uint32_t k = 0; ok && k < ns; k++) ok = hipMemcpy(&v[k], r->Lbuf.p + at0 + (size_t)k * stride, sizeof(vec4), hipMemcpyDeviceToHost) == hipSuccess;
+        if (!ok) (void)hipGetLastError();   // an analysis aid must not leave an error for the next batch's hipGetLastError()
+        for (uint32_t k = 0; ok && k < ns; k++) {
+          uint32_t b[3]; memcpy(b, &v[k], 12);
+          fprintf(stderr, "ptamd pixel %u,%u sample %u: %08x %08x %08x  %.9g %.9g %.9g\n", x, y, r->last_batch_first + k, b[0], b[1], b[2], v[k].x, v[k].y, v[k].z);
+        }
       }
     }
   }
+#endif
   if (r->started)
     r->timer_ms = (uint64_t)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r->render_start).count();
   return PT_OK;

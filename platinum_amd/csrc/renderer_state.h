@@ -166,6 +166,7 @@ struct pt_renderer {
     bvh = LbvhResult{};
     acc = nullptr;
     started = false;
+    last_batch_ns = 0;
   }
   // bytes of path-queue memory this renderer already holds (reused by the next render: they count as free when the batch is sized)
   size_t queue_bytes_held() const {
