@@ -74,6 +74,17 @@ PT_HD void triangle_ids(const DeviceScene& S, uint32_t tri, int32_t* inst, int32
 // box): tools/experiments/r05_own_box_hit_rule.patch, correct and 12 % slower).
 constexpr float kCullSlack = 1.0001f;
 
+// Slack of the slab comparison tn <= tf * kSlabSlack in the node steps.  Error budget of one plane distance in "ray space" (trav_node / trav_node6:
+// t = fma(q, A, B) with A = 2^k * inv, B = (origin - o) * inv; u = 2^-24 = half an ulp): inv = v_rcp_f32(d) is within 1 ulp = 2u of 1 / d (r5; an IEEE
+// division would be u), A inherits that exactly (a power-of-two scale), B adds the subtraction and the product (4u), the fma rounds once: with
+// both terms of one sign |dt| <= 5u t per plane.  The comparison sets the entry on one axis against the exit on ANOTHER (independent errors): 10u t =
+// 6.0e-7 t.  r1-r5 carried 1.0000005 (8.4u: sized for the 0.5-ulp reciprocal's 2 x 4u — ADVICE r5); r6 widens it to 1.000001 (16.8u).  Where the two
+// terms of the fma CANCEL (ray origin beyond the node's origin plane) the error is relative to the terms, not to t: in position space
+// <= 4u (node extent + |origin - o|), which is what the 8e-6 relative inflation of every box (inflate_box: 134u of the coordinate magnitude) is for.
+// Neither is a proof for a box hugging a coordinate plane seen from far away; the answer there rests on the hit contract's own tolerance
+// (kCullSlack) and on the sweeps (tests/test_stage_functions_host.py perturbs the reciprocal by +-1 ulp: no hit, no radiance bit changes).
+constexpr float kSlabSlack = 1.000001f;
+
 // Conservative slab test: entry distance or -1 if missed. fmin/fmax drop the NaN of 0 * inf.
 PT_HD float slab_entry(const float lo[3], const float hi[3], vec3 o, vec3 inv, float tmin, float tmax) {
   float t0 = (lo[0] - o.x) * inv.x, t1 = (hi[0] - o.x) * inv.x;
@@ -259,6 +270,9 @@ PT_HD bool trav_init(const DeviceScene& S, TravState& ts, vec3 o, vec3 d, float 
   ts.inv = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
 #else
   ts.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+#if defined(PT_TEST_PERTURB_RCP) && !defined(__HIP_DEVICE_COMPILE__)
+  PT_TEST_PERTURB_RCP(ts.inv);   // tests/emu only: the device's v_rcp_f32 may differ from 1 / d in the last bit — no answer may depend on it
+#endif
 #endif
   if (!(fabsf(ts.inv.x) <= 1e30f)) ts.inv.x = copysignf(1e30f, d.x);
   if (!(fabsf(ts.inv.y) <= 1e30f)) ts.inv.y = copysignf(1e30f, d.y);
@@ -383,7 +397,7 @@ PT_HD void trav_node(const BvhNode* __restrict__ nodes, TravState& ts, Traversal
     const float tnz = __builtin_fmaf((float)((nz >> (8 * k)) & 0xffu), az, bnz), tfz = __builtin_fmaf((float)((fz >> (8 * k)) & 0xffu), az, bfz);
     const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), ts.tmin);
     const float tf = fminf(fminf(fminf(tfx, tfy), tfz), far_lim);
-    const bool hit = n.ref[k] != kInvalidRef && tn <= __builtin_fmaf(tf, 1.0000005f, 1e-30f);
+    const bool hit = n.ref[k] != kInvalidRef && tn <= __builtin_fmaf(tf, kSlabSlack, 1e-30f);
     const bool leaf = hit && (n.ref[k] & kLeafBit);
     dist[k] = hit && !leaf ? tn : kInf;  // leaves never go on the node stack (TLAS leaves — kInstBit — do: they are entered like nodes)
     // queue the leaf (branch-free: a non-leaf writes to the scratch row kPendLeaves); two-level: as the flattened triangle
@@ -485,7 +499,7 @@ PT_HD void trav_node6(const BvhNode* __restrict__ nodes, TravState& ts, Traversa
     const float tnz = __builtin_fmaf((float)qnz, az, bz), tfz = __builtin_fmaf((float)qfz, az, bz);
     const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), ts.tmin);
     const float tf = fminf(fminf(fminf(tfx, tfy), tfz), far_lim);
-    const bool hit = (uint32_t)k < count && tn <= __builtin_fmaf(tf, 1.0000005f, 1e-30f);
+    const bool hit = (uint32_t)k < count && tn <= __builtin_fmaf(tf, kSlabSlack, 1e-30f);
     hits |= hit ? 1u << k : 0u;
     const bool nearer = hit && (uint32_t)k < n_int && tn < best_d;
     best_d = nearer ? tn : best_d;

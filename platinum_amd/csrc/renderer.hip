@@ -401,6 +401,13 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
       // slot and TWO 32-byte shade records (entry 2 * slot + half; the B entries unused) per triangle, 32 B more than a paired mesh
       const uint64_t flat_bytes = (uint64_t)r->tri_count * 292ull;
       r->two_level = invertible && (uint64_t)r->tri_count >= 8 * unique_tris && free_b != 0 && flat_bytes > free_b / 2;
+      // The switch is not silent: the two structures agree bit for bit except where fp32 Moeller-Trumbore reports a FALSE hit that
+      // lies outside an instance's tighter object-space boxes (fuzz seed 310601: one pixel-sample in ~1 500 scenes).
+      if (r->two_level && p->accel_structure == PT_ACCEL_AUTO && r->two_level_override < 0 && !getenv("PTAMD_QUIET"))
+        fprintf(stderr, "ptamd: PT_ACCEL_AUTO chose the TWO-LEVEL structure (flattening %u triangles would take %.1f GB of the %.1f GB free): 1.75x the "
+                        "traversal time of one BVH, and closest hits can differ from it where fp32 Moeller-Trumbore accepts a triangle the ray passes "
+                        "outside of (the seed-310601 class: ~1 pixel-sample per 1 500 scenes); PT_ACCEL_ONE_BVH / PT_ACCEL_TWO_LEVEL pin the choice\n",
+                r->tri_count, (double)flat_bytes / 1e9, (double)free_b / 1e9);
     }
     if (p->accel_structure == PT_ACCEL_ONE_BVH) r->two_level = false;
     else if (p->accel_structure == PT_ACCEL_TWO_LEVEL) r->two_level = invertible;

@@ -11,6 +11,22 @@
 #include <cstring>
 #include <vector>
 
+// $EMU_RCP_ULP = -1 / +1 (every component) / 2 (+-1 alternating by axis and sign; any even value: +- half of it): the ray's reciprocal direction moved by one ulp before the slab tests, as
+// the device's v_rcp_f32 may: hits and radiance must not change (tests/test_stage_functions_host.py)
+#include "../../platinum_amd/csrc/pt_math.h"
+static int g_emu_rcp_ulp = 0;
+static inline void emu_perturb_rcp(pt::vec3& inv) {
+  if (!g_emu_rcp_ulp) return;
+  float* c[3] = {&inv.x, &inv.y, &inv.z};
+  for (int a = 0; a < 3; a++) {
+    uint32_t b = pt::f2u(*c[a]);
+    if ((b & 0x7f800000u) == 0x7f800000u || (b & 0x7fffffffu) == 0) continue;
+    const int dir = (g_emu_rcp_ulp & 1) ? g_emu_rcp_ulp : (((a + (b >> 31)) & 1) ? g_emu_rcp_ulp / 2 : -g_emu_rcp_ulp / 2);   // odd: uniform; even: alternating +- half
+    b += (uint32_t)dir;   // magnitude +- 1 ulp
+    *c[a] = pt::u2f(b);
+  }
+}
+#define PT_TEST_PERTURB_RCP(v) emu_perturb_rcp(v)
 #include "../../platinum_amd/csrc/host_scene.h"
 #include "../../platinum_amd/csrc/pt_shade.h"
 
@@ -360,7 +376,7 @@ static RayHit wide_closest(const Emu& e, int store, int rule, vec3 o, vec3 d, fl
     for (int j = 0; j < 8; j++) {
       const int k = rule == 2 ? (j ^ oct) : j;   // rule 2: a ray going +x visits the low-x slots first
       if (n.ref[k] == kInvalidRef) continue;
-      const float tn = slab_entry(n.box[k].lo, n.box[k].hi, o, inv, tmin, best.t);
+      const float tn = slab_entry(n.box[k].lo, n.box[k].hi, o, inv, tmin, best.t * kCullSlack);   // (the shared traverse()'s cull rule: pt_bvh.h)
       if (tn < 0.0f) continue;
       if (n.ref[k] & kLeafBit) {
         static const std::vector<uint32_t> one(1, 0u);
@@ -391,6 +407,7 @@ extern "C" {
 void* emu_create(const pt_scene_snapshot* snap, const pt_render_params* p, const void* lut_blob, uint64_t lut_size) {
   auto* e = new Emu();
   e->params = *p;
+  g_emu_rcp_ulp = getenv("EMU_RCP_ULP") ? atoi(getenv("EMU_RCP_ULP")) : 0;
   const uint8_t* b = (const uint8_t*)lut_blob;
   uint32_t hdr[32]; memcpy(hdr, b + 12, sizeof(hdr));
   size_t off = 12 + 16 * 8, nf = (lut_size - off) / 4;
@@ -574,7 +591,7 @@ static RayHit probe_closest(const DeviceScene& S, vec3 o, vec3 d, float tmin, fl
       const float tny = __builtin_fmaf((float)((ny >> (8 * k)) & 0xffu), ay, by), tfy = __builtin_fmaf((float)((fy >> (8 * k)) & 0xffu), ay, by);
       const float tnz = __builtin_fmaf((float)((nz >> (8 * k)) & 0xffu), az, bz), tfz = __builtin_fmaf((float)((fz >> (8 * k)) & 0xffu), az, bz);
       const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), tmin);
-      const float tf = fminf(fminf(fminf(tfx, tfy), tfz), best.t);
+      const float tf = fminf(fminf(fminf(tfx, tfy), tfz), best.t * kCullSlack);
       const bool hit = n.ref[k] != kInvalidRef && tn <= __builtin_fmaf(tf, 1.0000005f, 1e-30f);
       if (!hit) continue;
       if (n.ref[k] & kLeafBit) leaves[nl++] = n.ref[k] & ~kLeafBit; else inner[ni++] = {tn, n.ref[k]};
@@ -587,7 +604,7 @@ static RayHit probe_closest(const DeviceScene& S, vec3 o, vec3 d, float tmin, fl
     while (!stack.empty()) {
       const auto e = stack.back(); stack.pop_back();
       // (the same conservative comparison the slab test uses: an entry is only dropped when its children could not pass it)
-      if (cull && !(e.second <= __builtin_fmaf(best.t, 1.0000005f, 1e-30f))) continue;
+      if (cull && !(e.second <= __builtin_fmaf(best.t * kCullSlack, 1.0000005f, 1e-30f))) continue;
       cur = e.first; got = true; break;
     }
     if (!got) return best;
@@ -791,7 +808,7 @@ void emu_packet_probe(void* h, uint32_t sample, double out[6]) {
               lo[a] = nd.origin[a] + (float)((nd.qlo[a] >> (8 * c)) & 0xffu) * node_scale(nd.exp[a]);
               hi[a] = nd.origin[a] + (float)((nd.qhi[a] >> (8 * c)) & 0xffu) * node_scale(nd.exp[a]);
             }
-            const float tn = slab_entry(lo, hi, q.o, q.inv, 1e-3f, q.best.t);
+            const float tn = slab_entry(lo, hi, q.o, q.inv, 1e-3f, q.best.t * kCullSlack);
             if (tn < 0.0f) continue;
             hitk[k][c] = true; any[c] = true; tmin_child[c] = fminf(tmin_child[c], tn);
           }

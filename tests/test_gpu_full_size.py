@@ -11,7 +11,9 @@
   * compares the ray / shadow-ray / shaded-hit counters of a full-size two-sample render with the oracle's whole-frame counters;
   * renders a second planned batch on top and compares the probe pixels again (the running mean's weights with samples already in it);
   * requires the whole 128-in-flight image to equal, bit for bit, the image the same library produces in batches of 16 (different segment
-    fill, different chunk tables, different accumulate folds — the same samples in the same order).
+    fill, different chunk tables, different accumulate folds — the same samples in the same order);
+  * (r6) compares 24 of the probe pixels x 4 samples with the oracle's BRUTE-FORCE loop over every triangle — the contract's definition of a
+    hit — so that the oracle's own tree is not the only reference at full size.
 """
 import os
 import sys
@@ -122,6 +124,17 @@ def _full_size_case(r, scene, W, H, B, spp_expected=None, counters_spp=2):
     ref2 = o.render_pixels(xy2, 0, 2 * S)
     got2 = acc2[xy2[:, 1], xy2[:, 0]]
     assert (((got2.view(np.uint32) == ref2.view(np.uint32)) | (np.isnan(got2) & np.isnan(ref2))).all(axis=1)).all()
+    # ---- the CONTRACT, not only the oracle's tree: a few of the probe pixels, first four samples, answered by the oracle's brute-force
+    #      loop over every triangle (min t, lowest id; any-hit = exists) — the definition the tree is merely a fast way to evaluate ------------------
+    xyb = xy[:: max(1, len(xy) // 24)][:24]
+    ob = oracle_lib.OracleScene(scene, make_params(W, H, 4, B), use_bvh=False)
+    refb = ob.render_pixels(xyb, 0, 4)
+    ob.close()
+    r.startRender(scene, (W, H), 4, max_bounces=B)
+    r.render(0)
+    r.wait()
+    gotb = r.readbackAccumulator()[xyb[:, 1], xyb[:, 0]]
+    assert (((gotb.view(np.uint32) == refb.view(np.uint32)) | (np.isnan(gotb) & np.isnan(refb))).all(axis=1)).all(), "HIP path != brute force"
     # ---- the same samples in batches of 16: the whole image, bit for bit --------------------------------------------------------------
     r.startRender(scene, (W, H), S, max_bounces=B, samples_in_flight=16)
     r.render(0)

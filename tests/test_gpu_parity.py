@@ -894,9 +894,11 @@ def test_where_the_oracles_tree_and_brute_force_part_the_product_follows_brute_f
     assert len(differing) <= 1 and np.nanmax(np.abs(tree - brute)) < 1e-5
     # the default structure (pair slots: a slot's box spans two triangles and reaches the false hit) follows brute force; with one triangle per slot
     # ($PTAMD_NO_PAIRS: boxes as tight as the oracle's) the product follows the oracle's tree instead — an any-hit answer depends on whether a
-    # structure's boxes reach a triangle fp32 wrongly accepts, and this seed shows both sides of it
+    # structure's boxes reach a triangle fp32 wrongly accepts, and this seed shows both sides of it.  Exactly ONE side is expected per structure
+    # (ADVICE r5); the session-wide structure presets of the sweeps (4-wide, radix tree, two-level ...) have boxes of their own: not claimed here.
+    skip_if_structure_env_preset()
     if "PTAMD_NO_PAIRS" in os.environ:
-        assert _same_bits_or_both_nan(acc, tree) or _same_bits_or_both_nan(acc, brute)
+        assert _same_bits_or_both_nan(acc, tree)
     else:
         assert _same_bits_or_both_nan(acc, brute)
 

@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/r06_ab.sh <tag> <workloads: "c3 c2"> <variant[:ENV=VAL,...]> ... — kernel times of library variants (tools/build_variant.sh; "default" = libptamd.so)
+# usage (GPU box): bash tools/ab.sh <tag> <workloads: "c3 c2"> <variant[:ENV=VAL,...]> ... — kernel times of library variants (tools/build_variant.sh; "default" = libptamd.so)
 tag=$1; wls=$2; shift 2
 for spec in "$@"; do
   v=${spec%%:*}; envs=""; [ "$spec" != "$v" ] && envs=${spec#*:}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/build_variant.sh <tag> [-DFLAG ...] — libptamd_<tag>.so = the library with kernels.hip (+ renderer.hip) compiled under extra flags
-# (experiments only; select with PTAMD_LIB=platinum_amd/csrc/libptamd_<tag>.so; tools/sweep_variants.sh benches them all)
+# (experiments only; select with PTAMD_LIB=platinum_amd/csrc/libptamd_<tag>.so; tools/ab.sh benches them)
 set -e
 tag=$1; shift
 cd "$(dirname "$0")/../platinum_amd/csrc"

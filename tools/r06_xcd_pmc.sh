@@ -5,7 +5,7 @@ timeout -k 10 300 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum 
 export PTAMD_LIB=$GRAFT_REPO_ROOT/platinum_amd/csrc/libptamd_xcd.so
 timeout -k 10 300 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/xcd_tc -- python3 bench.py --workload c3 --pmc-pass --steps 2 > $OUT/xcd.json 2> $OUT/xcd.err || echo "xcd pass failed"
 unset PTAMD_LIB
-for v in default xcd; do echo "#### $v"; python3 tools/pmc_agg2.py $OUT/${v}_tc k_trace; done > gpurun_out/r06_xcd_pmc.txt
+for v in default xcd; do echo "#### $v"; python3 tools/pmc_agg.py $OUT/${v}_tc k_trace; done > gpurun_out/r06_xcd_pmc.txt
 python3 - <<'PY'
 import json
 for v in ("default", "xcd"):

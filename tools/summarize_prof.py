@@ -12,7 +12,7 @@ half of the bytes of wide coalesced streaming reads.  The factor is CALIBRATED i
 1 GiB torch elementwise pass bench.py --pmc-pass runs (r5) — and a value outside [1.9, 2.1] stops this script; k_accumulate ((S+1) * 16 B read,
 16 B written per pixel) and k_raygen (64 B written per path) are reported beside it as second opinions.
 The traversal kernels read 64-B nodes / triangle slots as 16-B-per-lane gathers — a pattern the guide leaves uncalibrated;
-tools/calib_gather.hip calibrated it (profiles/r02_calib_gather.md): FETCH_SIZE is exact for it, so those kernels get x1."""
+tools/archive/calib_gather.hip calibrated it (profiles/r02_calib_gather.md): FETCH_SIZE is exact for it, so those kernels get x1."""
 import csv, glob, hashlib, json, os, shutil, sys
 from collections import defaultdict
 
