@@ -20,6 +20,8 @@ struct Segments {
   WaveStats* stats;     // [nstats] per physical wave of the producer kernels
   uint32_t* table_closest;  // dense lists of non-empty chunks, (k << 16) | segment, rebuilt by k_chunk_tables
   uint32_t* table_shadow;
+  uint32_t* shade_order;    // [nseg] the segments by falling size of the closest-hit queue: the order in which k_shade's waves claim them (k_chunk_tables)
+  uint32_t* shade_cost;     // [bounce][nseg] 100 MHz ticks k_shade spent on the segment at that bounce in the PREVIOUS batch of this render (0: none yet)
   uint32_t seg_cap;     // slots per segment (a multiple of 64) = tiles_per_seg * samples_in_flight * 64
   uint32_t nseg;        // segments (<= 32768: k_chunk_tables packs the id into 16 bits and scans <= 1024 per block)
   uint32_t tiles_per_seg;

@@ -72,6 +72,19 @@ __device__ __forceinline__ uint32_t seg_slot(uint32_t nseg, uint32_t s, uint32_t
 uint32_t seg_group_chunks() { return PT_SEG_GROUP; }
 static_assert(PT_SEG_GROUP == kSegGroupChunks, "queue_plan.h sizes the queue arrays for this interleaving");
 
+#ifdef PT_TAIL_PROBE
+#define PT_TAIL_BEGIN const unsigned long long tail_t0 = wall_clock64();
+#define PT_TAIL_END(kind)                                                                                         \
+  if (wave_lane() == 0 && bounce < 16u) {                                                                           \
+    const unsigned long long t1 = wall_clock64();                                                                   \
+    atomicMax(&ctr->tail_end_max[kind][bounce], t1); atomicAdd(&ctr->tail_end_sum[kind][bounce], t1);              \
+    atomicMax(&ctr->tail_start_inv[kind][bounce], ~tail_t0); atomicAdd(&ctr->tail_waves[kind][bounce], 1ull);     \
+  }
+#else
+#define PT_TAIL_BEGIN
+#define PT_TAIL_END(kind)
+#endif
+
 // ---- chunk claims for the trace kernels ------------------------------------------------------------------------------
 // 64-ray chunks claimed per cursor atomic.  ONE L2 address sustains ~88 returning atomics per microsecond
 // (MI355X_MICROARCH.md "dequeue"); at 2 chunks per claim the C2 closest-hit kernel (10.6 Grays/s = 166 chunks/us) ran AT that
@@ -144,6 +157,31 @@ struct ChunkClaims {
 constexpr uint32_t kTableBlocks = 32;
 __global__ void __launch_bounds__(1024) k_chunk_tables(Segments seg, uint32_t cur, BatchCounters* __restrict__ ctr,
                                                         uint32_t bounce_closest, uint32_t bounce_shadow, uint32_t do_shadow) {
+  if (blockIdx.y == 2) {
+    // ---- the order in which k_shade's waves take the segments of the closest-hit queue: LONGEST FIRST.  A segment is one wave's sequential work
+    //      there; with the plain segment order the chip waited 10 % (C3) to 14 % (C2) of every k_shade launch — 15-29 % from bounce 3 on, where the
+    //      segments differ by an order of magnitude — for the waves that had drawn a long segment last (r6, -DPT_TAIL_PROBE).  Key: the time k_shade
+    //      measured for this segment at this bounce in the PREVIOUS batch of the render (same camera, same scene: the same work), else the
+    //      segment's size.  A counting sort over 240 logarithmic classes (5 bits of exponent, 3 of mantissa); the order inside a class is whatever
+    //      the atomics make it — no result depends on the order in which segments are shaded.
+    if (blockIdx.x != 0) return;
+    const uint32_t* __restrict__ cnt = seg.active[cur];
+    const uint32_t* __restrict__ cost = seg.shade_cost + (size_t)bounce_closest * seg.nseg;
+    __shared__ uint32_t hist[256];
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    __syncthreads();
+    auto size_class = [&](uint32_t w) {
+      const uint32_t c = cost[w], v = c ? c : cnt[w];
+      const uint32_t e = 31u - (uint32_t)__builtin_clz(v | 8u);
+      return 255u - (v < 8u ? v : (e - 2u) * 8u + ((v >> (e - 3u)) & 7u));
+    };
+    for (uint32_t w = threadIdx.x; w < seg.nseg; w += 1024) atomicAdd(&hist[size_class(w)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int b = 0; b < 256; b++) { const uint32_t h = hist[b]; hist[b] = run; run += h; } }
+    __syncthreads();
+    for (uint32_t w = threadIdx.x; w < seg.nseg; w += 1024) seg.shade_order[atomicAdd(&hist[size_class(w)], 1u)] = w;
+    return;
+  }
   const bool sh = blockIdx.y == 1;
   if (sh && !do_shadow) return;
   const uint32_t* __restrict__ counts = sh ? seg.shadow : seg.active[cur];
@@ -360,6 +398,7 @@ template <bool COUNT, bool TWO, bool W6 = false>
 __global__ void __launch_bounds__(TWO ? kTraceBlock2 : kBlock, TWO ? PT_TWO_BLOCKS_PER_CU : PT_CLOSEST_WAVES)
 k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments seg, uint32_t cur, BatchCounters* __restrict__ ctr, uint32_t bounce,
                 uint32_t* __restrict__ spill, int32_t* __restrict__ hitlog, uint32_t log_stride) {
+  PT_TAIL_BEGIN
   constexpr uint32_t kTB = TWO ? kTraceBlock2 : kBlock;
   __shared__ uint32_t lds_stack[(W6 ? kLdsStack6 : kLdsStack) + 1][kTB];
   __shared__ uint32_t lds_pend[(W6 ? kPendLeaves6 : kPendLeaves) + 1][kTB];
@@ -429,6 +468,7 @@ k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments se
       atomicAdd(&ctr->tris_closest, (unsigned long long)t);
     }
   }
+  PT_TAIL_END(0)
 }
 
 // ---- shade -----------------------------------------------------------------------------------------------------------
@@ -455,6 +495,7 @@ constexpr uint32_t kBinCap = 128;       // a bin is emptied as soon as it holds 
 __global__ void __launch_bounds__(PT_SHADE_BLOCK, (PT_SHADE_WAVES * 4 * 64) / PT_SHADE_BLOCK)
 k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const vec4* __restrict__ hit, ShadowQueue sq,
         vec4* __restrict__ Lbuf, Segments seg, uint32_t cur, BatchCounters* __restrict__ ctr, uint32_t bounce) {
+  PT_TAIL_BEGIN
   const DeviceScene& S = *Sp;  // scene table read through the scalar cache: by value it cost 100 spilled SGPRs here
   __shared__ HaltonEntry lds_halton[kShadeHalton];
   __shared__ LightRec lds_lights[kShadeLights];
@@ -498,10 +539,12 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
   uint32_t shaded = 0, total_out = 0, total_shadow = 0;
   // first segment = the wave's index; further ones are claimed from a per-launch cursor (segments differ in size by the
   // time the later bounces are reached, so a static deal would leave waves idle at the end of every launch)
-  uint32_t sg = wave_index();
+  uint32_t claim = wave_index();   // position in seg.shade_order: the segments by falling size (k_chunk_tables)
   uint16_t* bin = &lds_bins[threadIdx.x >> 6][0][0];  // this wave's bins: [class][kBinCap] slot numbers within the segment
   uint32_t* bin_tri = &lds_bin_tri[threadIdx.x >> 6][0][0];
-  while (sg < seg.nseg) {
+  while (claim < seg.nseg) {
+    const uint32_t sg = __builtin_amdgcn_readfirstlane(seg.shade_order[claim]);
+    const unsigned long long seg_t0 = wall_clock64();
     const uint32_t lbuf_base = segment_lbuf_base(seg, sg);  // this segment's window of the per-sample radiance buffer
     const uint32_t n = __builtin_amdgcn_readfirstlane(seg.active[cur][sg]);  // (a scalar for the compiler too: the scan loop and the bin counters stay in SGPRs)
     uint32_t n_out = 0, n_shadow = 0;
@@ -657,12 +700,13 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
       seg.active[cur ^ 1][sg] = n_out;
       seg.shadow[sg] = n_shadow;
       if (poisoned_now) seg.poison[sg] = 1u;
+      seg.shade_cost[(size_t)bounce * seg.nseg + sg] = (uint32_t)(wall_clock64() - seg_t0) + 1u;   // the next batch's sort key (k_chunk_tables)
     }
     total_out += n_out;
     total_shadow += n_shadow;
     uint32_t next = 0;
     if (lane == 0) next = wave_count() + atomicAdd(&ctr->work_shade[bounce], 1u);
-    sg = __builtin_amdgcn_readfirstlane(next);
+    claim = __builtin_amdgcn_readfirstlane(next);
   }
   if (lane == 0) {
     WaveStats& ws = seg.stats[wave_index()];
@@ -670,6 +714,7 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
     ws.shadow += total_shadow;
     ws.shaded += shaded;
   }
+  PT_TAIL_END(1)
 }
 
 // ---- shadow (any hit) --------------------------------------------------------------------------------------------------
@@ -677,6 +722,7 @@ template <bool COUNT, bool TWO, bool W6 = false>
 __global__ void __launch_bounds__(TWO ? kTraceBlock2 : kBlock, TWO ? PT_TWO_BLOCKS_PER_CU : PT_SHADOW_WAVES)
 k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments seg, BatchCounters* __restrict__ ctr, uint32_t bounce,
                uint32_t* __restrict__ spill) {
+  PT_TAIL_BEGIN
   constexpr uint32_t kTB = TWO ? kTraceBlock2 : kBlock;
   __shared__ uint32_t lds_stack[(W6 ? kLdsStack6 : kLdsStack) + 1][kTB];
   __shared__ uint32_t lds_pend[(W6 ? kPendLeaves6 : kPendLeaves) + 1][kTB];
@@ -734,6 +780,7 @@ k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments 
       atomicAdd(&ctr->tris_shadow, (unsigned long long)t);
     }
   }
+  PT_TAIL_END(2)
 }
 
 // ---- accumulate (kernel.metal:672-684): running mean, one sample at a time, in sample order --------------------------
@@ -982,7 +1029,7 @@ void launch_raygen(hipStream_t s, uint32_t grid, const DeviceScene& S, PathState
 }
 void launch_chunk_tables(hipStream_t s, Segments seg, uint32_t cur, BatchCounters* ctr, uint32_t bounce_closest,
                          uint32_t bounce_shadow, bool do_shadow) {
-  hipLaunchKernelGGL(k_chunk_tables, dim3(kTableBlocks, 2), dim3(1024), 0, s, seg, cur, ctr, bounce_closest, bounce_shadow, do_shadow ? 1u : 0u);
+  hipLaunchKernelGGL(k_chunk_tables, dim3(kTableBlocks, 3), dim3(1024), 0, s, seg, cur, ctr, bounce_closest, bounce_shadow, do_shadow ? 1u : 0u);
 }
 // One-BVH scenes: `grid` blocks of 256 threads (7 per CU).  Two-level scenes (S.two_level): one 1024-thread block per CU.
 uint32_t trace_block_threads(bool two_level) { return two_level ? kTraceBlock2 : (uint32_t)kBlock; }

@@ -83,7 +83,10 @@ constexpr float kCullSlack = 1.0001f;
 // <= 4u (node extent + |origin - o|), which is what the 8e-6 relative inflation of every box (inflate_box: 134u of the coordinate magnitude) is for.
 // Neither is a proof for a box hugging a coordinate plane seen from far away; the answer there rests on the hit contract's own tolerance
 // (kCullSlack) and on the sweeps (tests/test_stage_functions_host.py perturbs the reciprocal by +-1 ulp: no hit, no radiance bit changes).
-constexpr float kSlabSlack = 1.000001f;
+#ifndef PT_SLAB_SLACK
+#define PT_SLAB_SLACK 1.000001f
+#endif
+constexpr float kSlabSlack = PT_SLAB_SLACK;
 
 // Conservative slab test: entry distance or -1 if missed. fmin/fmax drop the NaN of 0 * inf.
 PT_HD float slab_entry(const float lo[3], const float hi[3], vec3 o, vec3 inv, float tmin, float tmax) {

@@ -263,6 +263,9 @@ struct BatchCounters {
   uint32_t nonfinite;     // samples with NaN/inf radiance seen by k_accumulate
   uint32_t _pad[2];
   unsigned long long nodes_closest, tris_closest, nodes_shadow, tris_shadow;  // instrumented runs only
+#ifdef PT_TAIL_PROBE   // analysis build only (tools/build_variant.sh tail -DPT_TAIL_PROBE): when do the waves of a persistent launch run out of work?
+  unsigned long long tail_end_max[3][16], tail_end_sum[3][16], tail_start_inv[3][16], tail_waves[3][16];   // [closest, shade, shadow][bounce]; 100 MHz ticks
+#endif
 };
 
 struct Totals {  // running totals since pt_start_render (folded from BatchCounters after each batch)

@@ -498,6 +498,10 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   PT_HIP(r->seg_poison.alloc(r->nseg));
   PT_HIP(r->wave_stats.alloc(r->nstats));
   for (int k = 0; k < 2; k++) PT_HIP(r->chunk_table[k].alloc(r->capacity / 64));
+  PT_HIP(r->shade_order.alloc(r->nseg));
+  // (max_bounces + 1 rows: the table pass after the LAST bounce's k_shade still sorts for a bounce nobody runs, and reads that row)
+  PT_HIP(r->shade_cost.alloc((size_t)r->nseg * (r->S.max_bounces + 1u)));
+  PT_HIP(hipMemsetAsync(r->shade_cost.p, 0, sizeof(uint32_t) * r->shade_cost.n, r->stream));   // no batch of this render has been shaded yet
   PT_HIP(r->spill.alloc((size_t)std::max(r->closest_grid, r->shadow_grid) * trace_block_threads(r->two_level) * kSpillStack));  // per-thread HBM stack slab behind the LDS stack
   PT_HIP(hipMemsetAsync(r->wave_stats.p, 0, sizeof(WaveStats) * r->nstats, r->stream));
   if (p->external_accumulator) {
@@ -589,6 +593,25 @@ int dev_wait(pt_renderer* r) {
       fprintf(stderr, "\n");
     }
   }
+#ifdef PT_TAIL_PROBE   // analysis build only: per launch of the LAST batch, how long the chip waited for its last wave after the average wave had run out of work
+  if (r->started) {
+    BatchCounters h{};
+    if (hipMemcpy(&h, r->ctr.p, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+      const char* names[3] = {"closest", "shade", "shadow"};
+      for (int k = 0; k < 3; k++) {
+        double tot = 0, tail = 0;
+        fprintf(stderr, "ptamd tail %s:", names[k]);
+        for (uint32_t b = 0; b < r->S.max_bounces && b < 16; b++) {
+          if (!h.tail_waves[k][b]) continue;
+          const double t0 = (double)(~h.tail_start_inv[k][b]), t1 = (double)h.tail_end_max[k][b], mean = (double)h.tail_end_sum[k][b] / (double)h.tail_waves[k][b];
+          fprintf(stderr, " b%u %.2f ms, idle tail %.1f %%;", b, (t1 - t0) / 1e5, 100.0 * (t1 - mean) / (t1 - t0));
+          tot += t1 - t0; tail += t1 - mean;
+        }
+        fprintf(stderr, "  all: %.2f ms, %.1f %% idle tail\n", tot / 1e5, tot > 0 ? 100.0 * tail / tot : 0.0);
+      }
+    } else (void)hipGetLastError();
+  }
+#endif
 #ifdef PT_DEBUG_PID   // debug build only (tools/build_variant.sh dbg -DPT_DEBUG_PID), like $PTAMD_DEBUG_RAY: nothing of it ships in libptamd.so
   if (r->started && r->last_batch_ns) {
     if (const char* e = getenv("PTAMD_DEBUG_PIXEL")) {  // analysis aid: "x,y" -> the per-sample radiance of that pixel in the LAST batch

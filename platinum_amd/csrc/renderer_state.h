@@ -116,6 +116,7 @@ struct pt_renderer {
   DevBuf<uint32_t> spill, seg_active[2], seg_shadow, seg_poison;
   DevBuf<WaveStats> wave_stats;
   DevBuf<uint32_t> chunk_table[2];
+  DevBuf<uint32_t> shade_order, shade_cost;
   DevBuf<vec4> gmon_buckets_d;  // [bucket][pixel] with PT_FLAG_GMON (renderer_pt.cpp:824-830)
   float gmon_cap = 1.0f;        // GmonOptions.cap (pt_shader_defs.hpp:164-166)
   pt_post_options post{};
@@ -155,7 +156,7 @@ struct pt_renderer {
 
   PathState path_state(int k) { return PathState{st_rayO[k].p, st_rayD[k].p, st_att[k].p}; }
   ShadowQueue shadow_queue() { return ShadowQueue{sq_o.p, sq_d.p, sq_c.p}; }
-  Segments segments() { return Segments{{seg_active[0].p, seg_active[1].p}, seg_shadow.p, seg_poison.p, wave_stats.p, chunk_table[0].p, chunk_table[1].p, seg_cap, nseg, tiles_per_seg, /*nsamples: set per batch*/ 0u, seg_bands, nstats, refill_threshold}; }
+  Segments segments() { return Segments{{seg_active[0].p, seg_active[1].p}, seg_shadow.p, seg_poison.p, wave_stats.p, chunk_table[0].p, chunk_table[1].p, shade_order.p, shade_cost.p, seg_cap, nseg, tiles_per_seg, /*nsamples: set per batch*/ 0u, seg_bands, nstats, refill_threshold}; }
 
   // A restart keeps every device array (they are re-filled, and only re-allocated when they must grow); what it drops is the
   // acceleration structure of the previous scene and the "started" state.  release_all() returns the memory (pt_destroy).
@@ -181,7 +182,7 @@ struct pt_renderer {
     inst_trav.release(); prim_tri_d.release(); mesh_prim_base_d.release(); inst_prim_base_d.release();
     bvh_scratch.release();
     for (int k = 0; k < 2; k++) { st_rayO[k].release(); st_rayD[k].release(); st_att[k].release(); }
-    seg_active[0].release(); seg_active[1].release(); seg_shadow.release(); seg_poison.release(); wave_stats.release(); chunk_table[0].release(); chunk_table[1].release(); gmon_buckets_d.release(); render_target.release();
+    seg_active[0].release(); seg_active[1].release(); seg_shadow.release(); seg_poison.release(); wave_stats.release(); chunk_table[0].release(); chunk_table[1].release(); shade_order.release(); shade_cost.release(); gmon_buckets_d.release(); render_target.release();
     hit.release(); sq_o.release(); sq_d.release(); sq_c.release(); Lbuf.release(); acc_own.release(); spill.release();
   }
   void drop_timed() {
