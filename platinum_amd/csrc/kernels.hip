@@ -73,16 +73,22 @@ uint32_t seg_group_chunks() { return PT_SEG_GROUP; }
 static_assert(PT_SEG_GROUP == kSegGroupChunks, "queue_plan.h sizes the queue arrays for this interleaving");
 
 #ifdef PT_TAIL_PROBE
-#define PT_TAIL_BEGIN const unsigned long long tail_t0 = wall_clock64();
+#define PT_TAIL_BEGIN const unsigned long long tail_t0 = wall_clock64(); unsigned long long tail_take = 0, tail_setup = 0, tail_ta = 0;
+#define PT_TAIL_T(acc) { const unsigned long long tb_ = wall_clock64(); acc += tb_ - tail_ta; tail_ta = tb_; }
+#define PT_TAIL_MARK tail_ta = wall_clock64();
 #define PT_TAIL_END(kind)                                                                                         \
   if (wave_lane() == 0 && bounce < 16u) {                                                                           \
     const unsigned long long t1 = wall_clock64();                                                                   \
     atomicMax(&ctr->tail_end_max[kind][bounce], t1); atomicAdd(&ctr->tail_end_sum[kind][bounce], t1);              \
     atomicMax(&ctr->tail_start_inv[kind][bounce], ~tail_t0); atomicAdd(&ctr->tail_waves[kind][bounce], 1ull);     \
+    atomicAdd(&ctr->tail_take[kind][bounce], tail_take); atomicAdd(&ctr->tail_setup[kind][bounce], tail_setup);     \
+    atomicAdd(&ctr->tail_busy[kind][bounce], t1 - tail_t0);                                                         \
   }
 #else
 #define PT_TAIL_BEGIN
 #define PT_TAIL_END(kind)
+#define PT_TAIL_T(acc)
+#define PT_TAIL_MARK
 #endif
 
 // ---- chunk claims for the trace kernels ------------------------------------------------------------------------------
@@ -93,16 +99,19 @@ static_assert(PT_SEG_GROUP == kSegGroupChunks, "queue_plan.h sizes the queue arr
 // (a fixed 8 costs C3 3 % in the tail; guided, C2 closest-hit went from 36.2 to 23.0 ms per step, shadow from 26.0 to 15.4).
 constexpr uint32_t kClaimMax = 8;
 
+// A chunk-table entry: segment (16 bits: nseg <= 32768), chunk within the segment (10 bits: seg_cap <= 65536), rays in the chunk - 1 (6 bits).
+__device__ __forceinline__ uint32_t chunk_entry(uint32_t sg, uint32_t k, uint32_t rays) { return ((rays - 1u) << 26) | (k << 16) | sg; }
+static_assert(kMaxSegments <= 65536 && kMaxSegmentSlots / 64 <= 1024, "chunk_entry packs 16 + 10 + 6 bits");
+
 struct ChunkClaims {
-  const uint32_t* __restrict__ table;   // [total] (k << 16) | s  for every non-empty chunk, segment-major
-  const uint32_t* __restrict__ counts;  // [nseg] rays per segment
+  const uint32_t* __restrict__ table;   // [total + 8] chunk_entry(segment, chunk, rays) for every non-empty chunk, segment-major
   uint32_t* cursor;
   uint32_t nseg, total, lane;
-  uint32_t next_c, end_c;
+  uint32_t next_c, end_c, run_c = 0;
+  uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0, e6 = 0, e7 = 0;   // the entries of the run being consumed (wave-uniform: scalar registers)
   uint32_t claim_k = kClaimMax, nwaves_grid = 1;
-  __device__ __forceinline__ void init(const uint32_t* tab, uint32_t total_, const uint32_t* c, uint32_t* cur, const Segments& seg,
-                                       uint32_t lane_) {
-    table = tab; total = total_; counts = c; cursor = cur; nseg = seg.nseg; lane = lane_;
+  __device__ __forceinline__ void init(const uint32_t* tab, uint32_t total_, uint32_t* cur, const Segments& seg, uint32_t lane_) {
+    table = tab; total = total_; cursor = cur; nseg = seg.nseg; lane = lane_;
     next_c = end_c = 0;
     nwaves_grid = gridDim.x * (blockDim.x >> 6);
     claim_k = guided(total);
@@ -128,16 +137,21 @@ struct ChunkClaims {
           if (lane == 0) base = atomicAdd(cursor, claim_k);
           base = __builtin_amdgcn_readfirstlane(base);
           if (base >= total) { exhausted = true; return got; }
-          next_c = base;
+          next_c = run_c = base;
           end_c = base + claim_k < total ? base + claim_k : total;
           claim_k = guided(total - end_c);
+          // the entries of the whole run in ONE load (lanes 0..7; the table is padded by kClaimMax entries): the wave waits for
+          // the claim and for this once per run of up to 8 chunks — with one entry + one segment count fetched per chunk it spent 5 % (C3) to
+          // 15 % (C2) of its time here (r6, -DPT_TAIL_PROBE)
+          const int ev = (int)table[base + (lane & 7u)];   // (one register; lanes 0..7 hold the run)
+          e0 = (uint32_t)__builtin_amdgcn_readlane(ev, 0); e1 = (uint32_t)__builtin_amdgcn_readlane(ev, 1); e2 = (uint32_t)__builtin_amdgcn_readlane(ev, 2);
+          e3 = (uint32_t)__builtin_amdgcn_readlane(ev, 3); e4 = (uint32_t)__builtin_amdgcn_readlane(ev, 4); e5 = (uint32_t)__builtin_amdgcn_readlane(ev, 5);
+          e6 = (uint32_t)__builtin_amdgcn_readlane(ev, 6); e7 = (uint32_t)__builtin_amdgcn_readlane(ev, 7);
         }
-        const uint32_t e = table[next_c++];
-        const uint32_t sg = e & 0xffffu, k = e >> 16;
-        const uint32_t n = counts[sg];
-        const uint32_t left = n - k * 64u;  // > 0: the table lists non-empty chunks only
-        pool_next = seg_slot(nseg, sg, k * 64u);
-        pool_end = pool_next + (left < 64u ? left : 64u);
+        const uint32_t at = next_c++ - run_c;
+        const uint32_t e = at == 0u ? e0 : at == 1u ? e1 : at == 2u ? e2 : at == 3u ? e3 : at == 4u ? e4 : at == 5u ? e5 : at == 6u ? e6 : e7;
+        pool_next = seg_slot(nseg, e & 0xffffu, ((e >> 16) & 0x3ffu) * 64u);
+        pool_end = pool_next + (e >> 26) + 1u;
       }
       if (need && got == kInvalidRef) {
         const uint32_t idx = pool_next + wave_prefix(m);
@@ -214,7 +228,10 @@ __global__ void __launch_bounds__(1024) k_chunk_tables(Segments seg, uint32_t cu
     __syncthreads();
   }
   // inclusive scan of this slice's per-segment chunk counts (thread t <-> segment w_begin + t)
-  const uint32_t mine = (w_begin + threadIdx.x < w_end) ? (counts[w_begin + threadIdx.x] + 63u) / 64u : 0u;
+  __shared__ uint32_t rays_of[1024];   // rays of segment w_begin + t: an entry carries its chunk's ray count, so that the trace waves need no second look-up
+  const uint32_t mine_n = (w_begin + threadIdx.x < w_end) ? counts[w_begin + threadIdx.x] : 0u;
+  rays_of[threadIdx.x] = mine_n;
+  const uint32_t mine = (mine_n + 63u) / 64u;
   part[threadIdx.x] = mine;
   __syncthreads();
   for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele
@@ -230,7 +247,8 @@ __global__ void __launch_bounds__(1024) k_chunk_tables(Segments seg, uint32_t cu
     uint32_t lo = 0, hi = 1023;
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (part[mid] > e) hi = mid; else lo = mid + 1; }
     const uint32_t k = e - (lo ? part[lo - 1] : 0u);
-    table[base + e] = (k << 16) | (w_begin + lo);
+    const uint32_t left = rays_of[lo] - k * 64u;   // >= 1: only non-empty chunks are listed
+    table[base + e] = chunk_entry(w_begin + lo, k, left < 64u ? left : 64u);
   }
 }
 
@@ -406,7 +424,7 @@ k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments se
   const BvhNode* lds_nodes = TWO && kLdsNodes ? stage_nodes(S, lds_nodes_buf) : nullptr;
   const uint32_t lane = wave_lane();
   ChunkClaims src;
-  src.init(seg.table_closest, ctr->chunks_closest[bounce], seg.active[cur], &ctr->work_closest[bounce], seg, lane);
+  src.init(seg.table_closest, ctr->chunks_closest[bounce], &ctr->work_closest[bounce], seg, lane);
   TraversalStack stack;
   stack.lds = &lds_stack[0][threadIdx.x];
   stack.pend = &lds_pend[0][threadIdx.x];
@@ -437,7 +455,9 @@ k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments se
   };
   const uint32_t refill = seg.refill_threshold;
   for (;;) {
+    PT_TAIL_MARK
     const uint32_t fresh = src.take(ray == kInvalidRef);
+    PT_TAIL_T(tail_take)
     if (fresh != kInvalidRef) {
       ray = fresh;
       const vec4 o4 = st.rayO[ray];
@@ -450,6 +470,7 @@ k_trace_closest(DeviceScene S, PathState st, vec4* __restrict__ hit, Segments se
 #endif
       if (trav_init(S, ts, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 1e-3f, kInf, ir, stack, false, COUNT ? &tc : nullptr)) finish();
     }
+    PT_TAIL_T(tail_setup)
     if (__ballot(ray != kInvalidRef) == 0) {
       if (src.exhausted && src.pool_next == src.pool_end) break;
       continue;
@@ -730,7 +751,7 @@ k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments 
   const BvhNode* lds_nodes = TWO && kLdsNodes ? stage_nodes(S, lds_nodes_buf) : nullptr;
   const uint32_t lane = wave_lane();
   ChunkClaims src;
-  src.init(seg.table_shadow, ctr->chunks_shadow[bounce], seg.shadow, &ctr->work_shadow[bounce], seg, lane);
+  src.init(seg.table_shadow, ctr->chunks_shadow[bounce], &ctr->work_shadow[bounce], seg, lane);
   TraversalStack stack;
   stack.lds = &lds_stack[0][threadIdx.x];
   stack.pend = &lds_pend[0][threadIdx.x];
@@ -754,7 +775,9 @@ k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments 
   };
   const uint32_t refill = seg.refill_threshold;
   for (;;) {
+    PT_TAIL_MARK
     const uint32_t fresh = src.take(ray == kInvalidRef);
+    PT_TAIL_T(tail_take)
     if (fresh != kInvalidRef) {
       ray = fresh;
       const vec4 o4 = sq.o[ray];
@@ -763,6 +786,7 @@ k_trace_shadow(DeviceScene S, ShadowQueue sq, vec4* __restrict__ Lbuf, Segments 
       const float ir = S.has_alpha ? sq.contrib[ray].w : 0.0f;  // kernel.metal:625
       if (trav_init(S, ts, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), 1e-3f, o4.w, ir, stack, true, COUNT ? &tc : nullptr)) finish();
     }
+    PT_TAIL_T(tail_setup)
     if (__ballot(ray != kInvalidRef) == 0) {
       if (src.exhausted && src.pool_next == src.pool_end) break;
       continue;

@@ -265,6 +265,7 @@ struct BatchCounters {
   unsigned long long nodes_closest, tris_closest, nodes_shadow, tris_shadow;  // instrumented runs only
 #ifdef PT_TAIL_PROBE   // analysis build only (tools/build_variant.sh tail -DPT_TAIL_PROBE): when do the waves of a persistent launch run out of work?
   unsigned long long tail_end_max[3][16], tail_end_sum[3][16], tail_start_inv[3][16], tail_waves[3][16];   // [closest, shade, shadow][bounce]; 100 MHz ticks
+  unsigned long long tail_take[3][16], tail_setup[3][16], tail_busy[3][16];   // trace kernels: wave time in ChunkClaims::take, in ray load + trav_init, in all
 #endif
 };
 

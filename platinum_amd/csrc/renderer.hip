@@ -497,7 +497,7 @@ int dev_start_render(pt_renderer* r, const pt_scene_snapshot* scene, const pt_re
   PT_HIP(r->seg_shadow.alloc(r->nseg));
   PT_HIP(r->seg_poison.alloc(r->nseg));
   PT_HIP(r->wave_stats.alloc(r->nstats));
-  for (int k = 0; k < 2; k++) PT_HIP(r->chunk_table[k].alloc(r->capacity / 64));
+  for (int k = 0; k < 2; k++) PT_HIP(r->chunk_table[k].alloc(r->capacity / 64 + 8));   // + 8: a trace wave loads the entries of a whole run of up to 8 chunks, wherever the list ends
   PT_HIP(r->shade_order.alloc(r->nseg));
   // (max_bounces + 1 rows: the table pass after the LAST bounce's k_shade still sorts for a bounce nobody runs, and reads that row)
   PT_HIP(r->shade_cost.alloc((size_t)r->nseg * (r->S.max_bounces + 1u)));
@@ -607,7 +607,13 @@ int dev_wait(pt_renderer* r) {
           fprintf(stderr, " b%u %.2f ms, idle tail %.1f %%;", b, (t1 - t0) / 1e5, 100.0 * (t1 - mean) / (t1 - t0));
           tot += t1 - t0; tail += t1 - mean;
         }
-        fprintf(stderr, "  all: %.2f ms, %.1f %% idle tail\n", tot / 1e5, tot > 0 ? 100.0 * tail / tot : 0.0);
+        fprintf(stderr, "  all: %.2f ms, %.1f %% idle tail", tot / 1e5, tot > 0 ? 100.0 * tail / tot : 0.0);
+        if (k != 1) {
+          double take = 0, setup = 0, busy = 0;
+          for (uint32_t b = 0; b < r->S.max_bounces && b < 16; b++) { take += (double)h.tail_take[k][b]; setup += (double)h.tail_setup[k][b]; busy += (double)h.tail_busy[k][b]; }
+          if (busy > 0) fprintf(stderr, "; wave time: %.1f %% taking chunks, %.1f %% loading rays + set-up", 100.0 * take / busy, 100.0 * setup / busy);
+        }
+        fprintf(stderr, "\n");
       }
     } else (void)hipGetLastError();
   }
