@@ -22,7 +22,7 @@ steps with HIP events around every launch (on the renderer's stream).  Rank 0 pr
   roofline          the kernel with the largest device time, against every ceiling that could bind it
   roofline_kernels  the same block for each hot kernel (k_shade, k_trace_closest, k_trace_shadow)
   cpu_baseline      (N = 1) the product's own stage functions compiled for the host (tests/emu) on all host cores, bounded sample of the
-                    same workload (kind "same-kernels-host"); the scalar oracle's figure beside it under `oracle`
+                    same workload (kind "port", port_of "same-kernels-host"); the scalar oracle's figure beside it under `oracle`
 `roofline` is the contract's block for the dominant kernel: bound "hbm", achieved = HBM bytes the rocprofv3 counters saw per
 launch (FETCH_SIZE + WRITE_SIZE, corrected as MI355X_MICROARCH.md §HBM prescribes; committed per-item figures of
 profiles/<round>_pmc_<workload>.json x this run's items per launch) / this run's average launch time (HIP events), peak 8 TB/s,
@@ -683,7 +683,7 @@ def main():
         o = oracle_lib.OracleScene(scene, make_params(W, H, 64, B), use_bvh=True)
         n_o, dt_o, v_o, _ = bounded(lambda f, n, a, n0: o.render(f, n, acc=a, acc_n0=n0, threads=threads), args.cpu_seconds * 0.4)
         out["cpu_baseline"] = {
-            "value": round(v_e, 3), "unit": "Msamples/s", "cores": threads, "kind": "same-kernels-host", "cpu_model": cpu_model,
+            "value": round(v_e, 3), "unit": "Msamples/s", "cores": threads, "kind": "port", "port_of": "same-kernels-host", "cpu_model": cpu_model,
             "sample": "%dx%d x %d spp x %d bounces (sample indices 1..%d) of the same scene: the product's stage functions and 6-wide BVH traversal "
                       "(%s leaf slots) compiled for the host (tests/emu), std::thread over 16x16 tiles, %.1f s; host BVH build %.1f s not included"
                       % (W, H, n_e, B, n_e, "pair" if pairs else "one-triangle", dt_e, host_build_s),
