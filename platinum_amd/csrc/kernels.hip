@@ -11,15 +11,18 @@
 // the same segment of the other state buffer and its NEE rays into the same segment of the shadow queue.  Survivors <=
 // inputs, so a segment never overflows and NO atomic sits on the producer side.  (Round-1 measurement: with one global
 // append counter per queue, raygen and shade were pinned at the ~88 returning atomics/us one L2 address sustains —
-// MI355X_MICROARCH.md "dequeue"; raygen got 6.7x faster without it.)  The producers are persistent grids whose waves take
-// segments round-robin (wave w: segments w, w + P, w + 2P ...): there are 4-8x more segments than resident waves, so the
-// grid can be sized for whatever occupancy a kernel's registers allow and the tile count never has to divide it.
+// MI355X_MICROARCH.md "dequeue"; raygen got 6.7x faster without it.)  The producers are persistent grids: there are ~8x
+// more segments than resident waves, so the grid can be sized for whatever occupancy a kernel's registers allow and the
+// tile count never has to divide it.  k_raygen's waves take segments round-robin; k_shade's waves claim them LONGEST FIRST
+// from a list k_chunk_tables sorts after every producer (r6: in plain order the chip idled 10-14 % of every k_shade launch
+// waiting for the waves that had drawn a long segment last).
 // The trace kernels consume DENSE CHUNK TABLES: after every producer, k_chunk_tables lists the non-empty 64-entry
-// chunks of all segments, segment-major (= image tiles in raster order, each under its samples), and the trace waves
-// claim runs of that list from one cursor (8 chunks per atomic, fewer towards the end of the list): the rays in flight at any moment come from a
-// small neighbourhood of the image — the BVH subtrees they touch stay in L2 — there are no empty chunks to sweep, and
-// a chunk of survivors still comes from one tile.  Results are written in place (hit[i], Lbuf[pid]), so it does not
-// matter which wave traces a ray.  Statistics are kept per physical wave (no atomics) and reduced by k_fold_counters.
+// chunks of all segments, segment-major (= image tiles in raster order, each under its samples; an entry names its
+// segment, chunk and ray count), and the trace waves claim runs of that list from one cursor (8 chunks per atomic, fewer
+// towards the end of the list; a run's entries arrive in one load): the rays in flight at any moment come from a
+// small neighbourhood of the image, there are no empty chunks to sweep, and a chunk of survivors still comes from one
+// tile.  Results are written in place (hit[i], Lbuf[pid]), so it does not matter which wave traces a ray.  Statistics
+// are kept per physical wave (no atomics) and reduced by k_fold_counters.
 //
 // Compiled with -ffp-contract=off (deterministic fp32 contract, pt_math.h).
 #include <hip/hip_runtime.h>
@@ -558,9 +561,9 @@ k_shade(const DeviceScene* __restrict__ Sp, PathState sin, PathState sout, const
 
   const uint32_t lane = wave_lane();
   uint32_t shaded = 0, total_out = 0, total_shadow = 0;
-  // first segment = the wave's index; further ones are claimed from a per-launch cursor (segments differ in size by the
-  // time the later bounces are reached, so a static deal would leave waves idle at the end of every launch)
-  uint32_t claim = wave_index();   // position in seg.shade_order: the segments by falling size (k_chunk_tables)
+  // first claim = the wave's index; further ones come from a per-launch cursor (segments differ in size by the time the
+  // later bounces are reached, so a static deal would leave waves idle at the end of every launch)
+  uint32_t claim = wave_index();   // position in seg.shade_order: the segments, longest first (k_chunk_tables)
   uint16_t* bin = &lds_bins[threadIdx.x >> 6][0][0];  // this wave's bins: [class][kBinCap] slot numbers within the segment
   uint32_t* bin_tri = &lds_bin_tri[threadIdx.x >> 6][0][0];
   while (claim < seg.nseg) {
